@@ -1,0 +1,160 @@
+/*
+ * leann_backend.h — C ABI of the MI355X-native ANN search path that replaces leann-rs's
+ * backend layer (src/backend) and the arithmetic of its recompute search (src/index/recompute.rs).
+ *
+ * Every entry point cites the reference interface it replaces (path:line in decisiongraph/leann-rs).
+ * Plain pointers and sizes only; no torch / HIP types.  Thread-safety: `*_search*` are re-entrant
+ * on one handle (BackendSearcher: Send + Sync, src/backend/traits.rs:11; concurrent callers at
+ * src/cli/serve.rs:289-292); open/close/build are not.
+ *
+ * Return value: 0 on success, non-zero error code otherwise; the message is available from
+ * leann_last_error() (thread-local), mirroring the anyhow::Result strings of the reference.
+ *
+ * Distances: dist = 1 - <q, x> (MetricKind::IP, src/backend/hnsw.rs:45; DistDot,
+ * src/backend/diskann.rs:8,36), ascending, ties broken by lower key.  Keys are 0-based positions
+ * in embedding order (src/backend/hnsw.rs:129), widened to u64 (src/backend/diskann.rs:58).
+ */
+#ifndef LEANN_BACKEND_H
+#define LEANN_BACKEND_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct leann_backend leann_backend;
+
+/* enum BackendType { Hnsw, DiskAnn }  — src/backend/mod.rs:15-19 */
+enum { LEANN_BACKEND_HNSW = 0, LEANN_BACKEND_DISKANN = 1 };
+
+enum {
+    LEANN_OK = 0,
+    LEANN_ERR_INVALID = 1,      /* bad argument */
+    LEANN_ERR_NOT_FOUND = 2,    /* "Index file not found" hnsw.rs:34-40 / diskann.rs:26-32 */
+    LEANN_ERR_FORMAT = 3,       /* FAISS / foreign format, hnsw.rs:24-32,57-69; compat.rs:15-38 */
+    LEANN_ERR_DEVICE = 4,       /* HIP runtime / no GPU */
+    LEANN_ERR_UNSUPPORTED = 5,  /* e.g. DiskANN incremental add, mod.rs:93-98 */
+    LEANN_ERR_IO = 6
+};
+
+const char *leann_last_error(void);
+const char *leann_version(void);
+
+/* ---- BackendType::load_searcher(index_path, dimensions)  src/backend/mod.rs:23-45 -------------
+ * `index_path_stem` is ".../documents.leann"; the backend derives "<stem minus .leann>.index"
+ * (hnsw.rs:19) or ".diskann" (diskann.rs:22) itself.  `device_spec`: NULL / "" / "0" ... = HIP
+ * device ordinal. */
+int leann_backend_open(const char *index_path_stem, int backend, size_t dims,
+                       const char *device_spec, leann_backend **out);
+
+/* ---- BackendSearcher::search(&self, query, top_k, complexity)  src/backend/traits.rs:16-21 ----
+ * Caller allocates keys/dists[top_k]; the first *n_out are filled, best first; *n_out <= top_k
+ * (short results allowed, src/index/searcher.rs:139-143).  ef = max(complexity, top_k)
+ * (diskann.rs:54).  Unlike hnsw.rs:83 `complexity` is honoured for HNSW too. */
+int leann_backend_search(const leann_backend *h, const float *query, size_t top_k,
+                         size_t complexity, uint64_t *keys, float *dists, size_t *n_out);
+
+/* Additive: nq queries [nq x dims] row-major in one launch; equals nq single calls.
+ * keys/dists are [nq x top_k] (unused tail: key = UINT64_MAX, dist = +inf), counts[nq]. */
+int leann_backend_search_batch(const leann_backend *h, const float *queries, size_t nq,
+                               size_t top_k, size_t complexity, uint64_t *keys, float *dists,
+                               uint32_t *counts);
+
+/* BackendSearcher::len  src/backend/traits.rs:24 */
+size_t leann_backend_len(const leann_backend *h);
+size_t leann_backend_dims(const leann_backend *h);
+/* Drop of Box<dyn BackendSearcher> */
+void leann_backend_close(leann_backend *h);
+
+/* ---- BackendBuilder::build(embeddings, ids, index_path, dims, graph_degree, complexity)
+ *      src/backend/mod.rs:55-79 -> hnsw.rs:96-139 / diskann.rs:70-105 ---------------------------
+ * vectors: [n x dims] row-major host memory.  Writes "<stem>.index" / "<stem>.diskann". */
+int leann_backend_build(int backend, const float *vectors, size_t n, size_t dims,
+                        size_t graph_degree, size_t complexity, const char *index_path_stem);
+/* BackendBuilder::add_to_index(embeddings, index_path, dims, start_id)  mod.rs:82-100,
+ * hnsw.rs:142-191.  DiskANN -> LEANN_ERR_UNSUPPORTED with the reference's message. */
+int leann_backend_add(int backend, const float *vectors, size_t n, size_t dims, size_t start_id,
+                      const char *index_path_stem);
+
+/* ---- roofline accounting -------------------------------------------------------
+ * Totals accumulated over every search call on the handle since the last reset. */
+typedef struct {
+    uint64_t n_queries;
+    uint64_t n_dist_evals;   /* base vectors whose distance was computed (distinct per level) */
+    uint64_t n_hops_base;    /* expansions on level 0 */
+    uint64_t n_hops_upper;   /* expansions on levels >= 1 */
+    uint64_t n_table_overflow; /* queries re-run with the global-memory visited table */
+    uint64_t algorithmic_bytes; /* n_dist_evals*dims*4 + n_hops_base*M0*4 + n_hops_upper*M*4 */
+} leann_search_stats;
+int leann_backend_stats(const leann_backend *h, leann_search_stats *out, int reset);
+
+/* =================================================================================================
+ * Device-resident additive API (no reference counterpart): the same operations with operands that
+ * already live in HBM, on a caller-supplied HIP stream (void* = hipStream_t, NULL = default).
+ * Used by bench.py, the sharded searcher and the recompute path.
+ * ============================================================================================== */
+
+/* In-memory index straight from device-resident rows (no file round trip).
+ * d_vectors: [n x ld] f32 in HBM, ld % 4 == 0, ld >= dims, padding zero; borrowed if `take_copy`
+ * is 0 (must outlive the handle).  key_offset is added to every returned key (shard rebasing,
+ * SURVEY.md §8e). */
+int leann_backend_build_device(int backend, const float *d_vectors, size_t n, size_t dims,
+                               size_t ld, size_t graph_degree, size_t complexity, int device,
+                               uint64_t key_offset, int take_copy, leann_backend **out);
+/* Wrap host-side flat graph arrays + host rows into a device index. */
+int leann_backend_from_arrays(int backend, const float *vectors, size_t n, size_t dims,
+                              uint32_t M, uint32_t M0, uint32_t max_level, uint32_t entry,
+                              const uint8_t *levels, const uint32_t *upper_off,
+                              const uint32_t *adj0, const uint32_t *adjU, size_t n_upper_lists,
+                              int device, uint64_t key_offset, leann_backend **out);
+/* Copy the graph back to host arrays (sizes from leann_backend_graph_info). */
+int leann_backend_graph_info(const leann_backend *h, uint64_t *info /* n,dims,ld,M,M0,max_level,entry,n_upper_lists */);
+int leann_backend_graph_export(const leann_backend *h, uint8_t *levels, uint32_t *upper_off,
+                               uint32_t *adj0, uint32_t *adjU, float *vectors /* [n x dims] or NULL */);
+/* Persist an in-memory index: "<stem>.index" / ".diskann" */
+int leann_backend_save(const leann_backend *h, const char *index_path_stem);
+
+/* d_stats: optional [nq x 4] u32 (evals, hops0, hopsU, overflow) */
+int leann_backend_search_batch_device(const leann_backend *h, const float *d_queries, size_t nq,
+                                      size_t top_k, size_t complexity, uint64_t *d_keys,
+                                      float *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+                                      void *stream);
+/* device pointer of the rows (for ground-truth scans) */
+const float *leann_backend_device_rows(const leann_backend *h);
+
+/* Deterministic synthetic rows written straight into HBM; bit-identical to
+ * oracle/oracle.c:orc_gen_rows. */
+int leann_synth_rows_device(uint64_t seed, uint32_t dims, uint32_t ld, uint32_t r,
+                            uint32_t n_clusters, float sigma, uint32_t stream_id, uint64_t i0,
+                            uint64_t n, float *d_out, void *stream);
+
+/* Exact inner-product top-k of every query against all rows — the arithmetic of
+ * RecomputeSearcher::search, src/index/recompute.rs:96-109 (scores = raw dot, descending,
+ * ties -> lower position), with the embeddings already materialised in HBM.
+ * allow_mask: optional N-bit device bitmap (early filter, recompute.rs:66-71). */
+int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims, size_t ld,
+                           const float *d_queries, size_t nq, size_t top_k,
+                           const uint8_t *d_allow_mask, uint64_t key_offset, uint64_t *d_keys,
+                           float *d_scores, uint32_t *d_counts, void *stream);
+
+/* G-way merge of per-shard top-k lists gathered by RCCL: inputs
+ * [n_shards x nq x k_in], ascending (dist, key) per list (descending = 1 for recompute scores);
+ * outputs [nq x k_out]. */
+int leann_merge_topk_device(const uint64_t *d_keys, const float *d_dists, const uint32_t *d_counts,
+                            size_t n_shards, size_t nq, size_t k_in, size_t k_out, int descending,
+                            uint64_t *d_out_keys, float *d_out_dists, uint32_t *d_out_counts,
+                            void *stream);
+
+/* raw device memory helpers so that non-torch hosts (the C++ CLI, ctypes tests) need no HIP binding */
+int leann_device_count(int *n);
+int leann_device_malloc(int device, size_t bytes, void **out);
+int leann_device_free(void *p);
+int leann_device_upload(void *d_dst, const void *h_src, size_t bytes);
+int leann_device_download(void *h_dst, const void *d_src, size_t bytes);
+int leann_device_sync(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

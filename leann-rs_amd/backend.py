@@ -1,0 +1,197 @@
+"""Host-side mirror of leann-rs's backend layer (src/backend/{mod,traits,hnsw,diskann}.rs) over the
+C ABI.  Same names, argument meaning and error behaviour; the arithmetic runs in HIP kernels."""
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+
+from . import _native as N
+from ._native import LeannError, f32p, u32p, u64p, u8p
+
+
+class BackendType(enum.IntEnum):
+    """enum BackendType { Hnsw, DiskAnn } — src/backend/mod.rs:15-19"""
+    Hnsw = 0
+    DiskAnn = 1
+
+    @classmethod
+    def from_name(cls, name):
+        # src/index/searcher.rs:95-99
+        if name == "hnsw":
+            return cls.Hnsw
+        if name == "diskann":
+            return cls.DiskAnn
+        raise LeannError(1, f"Unknown backend: {name}")
+
+    def load_searcher(self, index_path, dimensions, device=0):
+        """BackendType::load_searcher — src/backend/mod.rs:23-45"""
+        return BackendSearcher.load(self, index_path, dimensions, device)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class BackendSearcher:
+    """trait BackendSearcher — src/backend/traits.rs:11-30 (HnswSearcher / DiskAnnSearcher)."""
+
+    def __init__(self, handle, backend_type):
+        self._h = handle
+        self.backend_type = BackendType(backend_type)
+
+    # -- constructors -------------------------------------------------------------------------
+    @classmethod
+    def load(cls, backend_type, index_path, dimensions, device=0):
+        """HnswSearcher::load (hnsw.rs:18-75) / DiskAnnSearcher::load (diskann.rs:21-43)."""
+        h = C.c_void_p()
+        N.check(N.lib().leann_backend_open(os.fsencode(str(index_path)), int(backend_type), dimensions,
+                                           str(device).encode(), C.byref(h)))
+        return cls(h, backend_type)
+
+    @classmethod
+    def from_arrays(cls, backend_type, vectors, M, M0, max_level, entry, levels, upper_off, adj0, adjU,
+                    device=0, key_offset=0):
+        vectors = np.ascontiguousarray(vectors, np.float32)
+        levels = np.ascontiguousarray(levels, np.uint8)
+        upper_off = np.ascontiguousarray(upper_off, np.uint32)
+        adj0 = np.ascontiguousarray(adj0, np.uint32)
+        adjU = np.ascontiguousarray(adjU, np.uint32)
+        nul = adjU.size // M if adjU.size else 0
+        h = C.c_void_p()
+        n, d = vectors.shape
+        N.check(N.lib().leann_backend_from_arrays(
+            int(backend_type), _p(vectors, f32p), n, d, M, M0, max_level, entry, _p(levels, u8p),
+            _p(upper_off, u32p), _p(adj0, u32p), _p(adjU, u32p) if nul else None, nul, device,
+            key_offset, C.byref(h)))
+        return cls(h, backend_type)
+
+    @classmethod
+    def build_device(cls, backend_type, d_vectors_ptr, n, dims, ld, graph_degree, complexity, device=0,
+                     key_offset=0, take_copy=False):
+        """Index straight from rows already in HBM (additive API)."""
+        h = C.c_void_p()
+        N.check(N.lib().leann_backend_build_device(int(backend_type), d_vectors_ptr, n, dims, ld,
+                                                   graph_degree, complexity, device, key_offset,
+                                                   1 if take_copy else 0, C.byref(h)))
+        return cls(h, backend_type)
+
+    # -- trait surface ------------------------------------------------------------------------
+    def search(self, query, top_k, complexity):
+        """fn search(&self, query, top_k, complexity) -> (Vec<u64>, Vec<f32>) — traits.rs:16-21"""
+        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if q.shape[0] != self.dims():
+            raise LeannError(1, f"query has {q.shape[0]} dimensions, index has {self.dims()}")
+        keys = np.zeros(max(top_k, 1), np.uint64)
+        dists = np.zeros(max(top_k, 1), np.float32)
+        n = C.c_size_t(0)
+        N.check(N.lib().leann_backend_search(self._h, _p(q, f32p), top_k, complexity, _p(keys, u64p),
+                                             _p(dists, f32p), C.byref(n)))
+        return keys[: n.value].copy(), dists[: n.value].copy()
+
+    def search_batch(self, queries, top_k, complexity):
+        Q = np.ascontiguousarray(queries, np.float32)
+        if Q.ndim != 2 or Q.shape[1] != self.dims():
+            raise LeannError(1, f"queries must be [nq x {self.dims()}]")
+        nq = Q.shape[0]
+        keys = np.full((nq, top_k), np.iinfo(np.uint64).max, np.uint64)
+        dists = np.full((nq, top_k), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        N.check(N.lib().leann_backend_search_batch(self._h, _p(Q, f32p), nq, top_k, complexity,
+                                                   _p(keys, u64p), _p(dists, f32p), _p(counts, u32p)))
+        return keys, dists, counts
+
+    def search_batch_device(self, d_queries, nq, top_k, complexity, d_keys, d_dists, d_counts,
+                            d_stats=None, stream=None):
+        N.check(N.lib().leann_backend_search_batch_device(self._h, d_queries, nq, top_k, complexity,
+                                                          d_keys, d_dists, d_counts, d_stats, stream))
+
+    def len(self):
+        return int(N.lib().leann_backend_len(self._h))
+
+    __len__ = len
+
+    def is_empty(self):
+        return self.len() == 0
+
+    def dims(self):
+        return int(N.lib().leann_backend_dims(self._h))
+
+    # -- extras -------------------------------------------------------------------------------
+    def stats(self, reset=False):
+        s = N.SearchStats()
+        N.check(N.lib().leann_backend_stats(self._h, C.byref(s), 1 if reset else 0))
+        return {k: int(getattr(s, k)) for k, _ in N.SearchStats._fields_}
+
+    def graph_info(self):
+        info = np.zeros(8, np.uint64)
+        N.check(N.lib().leann_backend_graph_info(self._h, _p(info, u64p)))
+        names = ("n", "dims", "ld", "M", "M0", "max_level", "entry", "n_upper_lists")
+        return {k: int(v) for k, v in zip(names, info)}
+
+    def graph_export(self, with_vectors=False):
+        gi = self.graph_info()
+        n = gi["n"]
+        levels = np.zeros(n, np.uint8)
+        upper_off = np.zeros(n, np.uint32)
+        adj0 = np.zeros((n, gi["M0"]), np.uint32)
+        adjU = np.zeros((max(gi["n_upper_lists"], 1), gi["M"]), np.uint32)
+        X = np.zeros((n, gi["dims"]), np.float32) if with_vectors else None
+        N.check(N.lib().leann_backend_graph_export(self._h, _p(levels, u8p), _p(upper_off, u32p),
+                                                   _p(adj0, u32p), _p(adjU, u32p), _p(X, f32p)))
+        return dict(gi, levels=levels, upper_off=upper_off, adj0=adj0, adjU=adjU[: gi["n_upper_lists"]],
+                    vectors=X)
+
+    def device_rows_ptr(self):
+        return N.lib().leann_backend_device_rows(self._h)
+
+    def save(self, index_path):
+        N.check(N.lib().leann_backend_save(self._h, os.fsencode(str(index_path))))
+
+    def close(self):
+        if self._h:
+            N.lib().leann_backend_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HnswSearcher(BackendSearcher):
+    """src/backend/hnsw.rs:12-14"""
+
+    @classmethod
+    def load(cls, index_path, dimensions, device=0):
+        return BackendSearcher.load.__func__(cls, BackendType.Hnsw, index_path, dimensions, device)
+
+
+class DiskAnnSearcher(BackendSearcher):
+    """src/backend/diskann.rs:15-17"""
+
+    @classmethod
+    def load(cls, index_path, dimensions, device=0):
+        return BackendSearcher.load.__func__(cls, BackendType.DiskAnn, index_path, dimensions, device)
+
+
+class BackendBuilder:
+    """struct BackendBuilder — src/backend/traits.rs:6-8, impl src/backend/mod.rs:48-101"""
+
+    def __init__(self, backend_type):
+        self.backend_type = BackendType(backend_type)
+
+    def build(self, embeddings, ids, index_path, dimensions, graph_degree, complexity):
+        """mod.rs:55-79 -> hnsw.rs:96-139 / diskann.rs:70-105.  `ids` is unused, as in the reference."""
+        X = np.ascontiguousarray(embeddings, np.float32)
+        if X.ndim != 2 or X.shape[1] != dimensions:
+            raise LeannError(1, f"embeddings must be [n x {dimensions}]")
+        N.check(N.lib().leann_backend_build(int(self.backend_type), _p(X, f32p), X.shape[0], dimensions,
+                                            graph_degree, complexity, os.fsencode(str(index_path))))
+
+    def add_to_index(self, embeddings, index_path, dimensions, start_id):
+        """mod.rs:82-100 -> hnsw.rs:142-191; DiskANN refuses (mod.rs:93-98)."""
+        X = np.ascontiguousarray(embeddings, np.float32)
+        N.check(N.lib().leann_backend_add(int(self.backend_type), _p(X, f32p), X.shape[0], dimensions,
+                                          start_id, os.fsencode(str(index_path))))

@@ -1,0 +1,524 @@
+// api.hip — C ABI (include/leann_backend.h) over the gfx950 kernels: handle lifetime, index files,
+// host<->HBM staging, kernel dispatch.  No CPU fallback exists in this library by design: every
+// search / scan / build entry point runs HIP kernels or returns LEANN_ERR_DEVICE.
+#include "common.cuh"
+#include "search.cuh"
+#include "../../include/leann_backend.h"
+#include "internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <sys/stat.h>
+
+static thread_local char g_err[2048] = "";
+extern "C" void leann_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *leann_last_error(void) { return g_err; }
+extern "C" const char *leann_version(void) { return "leann-rs_amd 0.1 (gfx950)"; }
+
+// ---- raw device helpers ---------------------------------------------------------------------------
+extern "C" int leann_device_count(int *n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { c = 0; (void)hipGetLastError(); }
+    *n = c;
+    return LEANN_OK;
+}
+extern "C" int leann_device_malloc(int device, size_t bytes, void **out) {
+    HIP_CHECK_RET(hipSetDevice(device));
+    HIP_CHECK_RET(hipMalloc(out, bytes ? bytes : 16));
+    return LEANN_OK;
+}
+extern "C" int leann_device_free(void *p) {
+    if (p) HIP_CHECK_RET(hipFree(p));
+    return LEANN_OK;
+}
+extern "C" int leann_device_upload(void *d, const void *h, size_t bytes) {
+    HIP_CHECK_RET(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+    return LEANN_OK;
+}
+extern "C" int leann_device_download(void *h, const void *d, size_t bytes) {
+    HIP_CHECK_RET(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+    return LEANN_OK;
+}
+extern "C" int leann_device_sync(int device) {
+    HIP_CHECK_RET(hipSetDevice(device));
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    return LEANN_OK;
+}
+
+// ---- handle (structs in internal.h) ---------------------------------------------------------------
+static void ws_free(Workspace *w) {
+    if (!w) return;
+    (void)hipFree(w->overflow_list);
+    (void)hipFree(w->ctrs);
+    (void)hipFree(w->gtables);
+    (void)hipFree(w->d_q);
+    (void)hipFree(w->d_keys);
+    (void)hipFree(w->d_dists);
+    (void)hipFree(w->d_counts);
+    (void)hipFree(w->d_stats);
+    if (w->stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+}
+static int ws_ensure(Workspace *w, size_t nq) {
+    if (!w->ctrs) {
+        HIP_CHECK_RET(hipMalloc((void **)&w->ctrs, 16));
+        HIP_CHECK_RET(hipMalloc((void **)&w->gtables, ((size_t)GT_BLOCKS << GT_BITS) * 4));
+    }
+    if (nq > w->cap_nq) {
+        (void)hipFree(w->overflow_list);
+        w->overflow_list = nullptr;
+        HIP_CHECK_RET(hipMalloc((void **)&w->overflow_list, nq * 4));
+        w->cap_nq = nq;
+    }
+    return LEANN_OK;
+}
+
+void leann_internal_free_graph(leann_backend *h) {
+    if (h->owns_rows) (void)hipFree((void *)h->g.X);
+    (void)hipFree((void *)h->g.adj0);
+    (void)hipFree((void *)h->g.adjU);
+    (void)hipFree((void *)h->g.upper_off);
+    (void)hipFree(h->d_levels);
+}
+
+extern "C" void leann_backend_close(leann_backend *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto *w : h->free_ws) ws_free(w);
+    for (auto &kv : h->stream_ws) ws_free(kv.second);
+    leann_internal_free_graph(h);
+    delete h;
+}
+extern "C" size_t leann_backend_len(const leann_backend *h) { return h ? (size_t)h->g.n : 0; }
+extern "C" size_t leann_backend_dims(const leann_backend *h) { return h ? (size_t)h->g.d : 0; }
+extern "C" const float *leann_backend_device_rows(const leann_backend *h) { return h ? h->g.X : nullptr; }
+
+extern "C" int leann_backend_stats(const leann_backend *hc, leann_search_stats *out, int reset) {
+    leann_backend *h = const_cast<leann_backend *>(hc);
+    if (!h || !out) { leann_set_error("leann_backend_stats: null argument"); return LEANN_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(h->mu);
+    *out = h->stats;
+    if (reset) h->stats = leann_search_stats{};
+    return LEANN_OK;
+}
+
+// ---- kernel dispatch --------------------------------------------------------------------------------
+static uint32_t pick_hash_bits(uint32_t ef) {
+    uint32_t want = ef * 64u, b = 10;
+    while ((1u << b) < want && b < 15) b++;
+    return b;
+}
+
+template <int T, int R>
+static int launch_search_T(const GraphView &g, SearchArgs a, Workspace *w, hipStream_t st) {
+    constexpr int NW = 4;
+    const uint32_t maxdeg = std::max(g.M0, g.M);
+    size_t lds1 = search_lds_bytes(a.ef, maxdeg, a.hash_bits, false);
+    size_t lds2 = search_lds_bytes(a.ef, maxdeg, GT_BITS, true);
+    if (lds1 > 160 * 1024) {
+        leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, lds1);
+        return LEANN_ERR_INVALID;
+    }
+    if (lds1 > 64 * 1024)
+        HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_lds_kernel<T, R, NW>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK_RET(hipMemsetAsync(w->ctrs, 0, 16, st));
+    a.overflow_list = w->overflow_list;
+    a.overflow_count = w->ctrs;
+    hipLaunchKernelGGL((beam_search_lds_kernel<T, R, NW>), dim3(a.nq), dim3(NW * 64), lds1, st, g, a);
+    SearchArgs b = a;
+    b.q_map = w->overflow_list;
+    b.q_map_count = w->ctrs;
+    b.work_counter = w->ctrs + 1;
+    b.gtables = w->gtables;
+    b.hash_bits = GT_BITS;
+    hipLaunchKernelGGL((beam_search_gtable_kernel<T, R, NW>), dim3(GT_BLOCKS), dim3(NW * 64), lds2, st, g, b);
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
+}
+
+int leann_internal_launch_search(const GraphView &g, SearchArgs a, Workspace *w, hipStream_t st) {
+    if (a.nq == 0) return LEANN_OK;
+    if (a.ef < a.k) a.ef = a.k; // diskann.rs:54
+    a.hash_bits = pick_hash_bits(a.ef);
+    int rc = ws_ensure(w, a.nq);
+    if (rc) return rc;
+    int T = (int)((g.ld + 255) / 256);
+    switch (T) {
+        case 1: return launch_search_T<1, 4>(g, a, w, st);
+        case 2: return launch_search_T<2, 4>(g, a, w, st);
+        case 3: return launch_search_T<3, 4>(g, a, w, st);
+        case 4: return launch_search_T<4, 3>(g, a, w, st);
+        case 5: case 6: return launch_search_T<6, 2>(g, a, w, st);
+        case 7: case 8: return launch_search_T<8, 2>(g, a, w, st);
+        default:
+            leann_set_error("search: dims %u > 2048 not supported", g.d);
+            return LEANN_ERR_INVALID;
+    }
+}
+
+Workspace *leann_internal_stream_ws(leann_backend *h, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    auto it = h->stream_ws.find(st);
+    if (it != h->stream_ws.end()) return it->second;
+    Workspace *w = new Workspace();
+    h->stream_ws[st] = w;
+    return w;
+}
+
+extern "C" int leann_backend_search_batch_device(const leann_backend *hc, const float *d_queries, size_t nq,
+                                                 size_t top_k, size_t complexity, uint64_t *d_keys, float *d_dists,
+                                                 uint32_t *d_counts, uint32_t *d_stats, void *stream) {
+    leann_backend *h = const_cast<leann_backend *>(hc);
+    if (!h || !d_queries || !d_keys || !d_dists || !d_counts || top_k == 0) {
+        leann_set_error("leann_backend_search_batch_device: null/zero argument");
+        return LEANN_ERR_INVALID;
+    }
+    if (nq == 0) return LEANN_OK;
+    HIP_CHECK_RET(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->g.n == 0) {
+        HIP_CHECK_RET(hipMemsetAsync(d_counts, 0, nq * 4, st));
+        return LEANN_OK;
+    }
+    Workspace *w = leann_internal_stream_ws(h, st);
+    SearchArgs a{};
+    a.queries = d_queries;
+    a.ldq = h->g.d;
+    a.nq = (uint32_t)nq;
+    a.k = (uint32_t)top_k;
+    a.ef = (uint32_t)std::max(complexity, top_k);
+    a.target_level = 0;
+    a.key_offset = h->key_offset;
+    a.out_keys = d_keys;
+    a.out_dists = d_dists;
+    a.out_counts = d_counts;
+    a.out_stats = d_stats;
+    return leann_internal_launch_search(h->g, a, w, st);
+}
+
+// BackendSearcher::search batched over host pointers.
+extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k,
+                                          size_t complexity, uint64_t *keys, float *dists, uint32_t *counts) {
+    leann_backend *h = const_cast<leann_backend *>(hc);
+    if (!h || !queries || !keys || !dists || !counts) {
+        leann_set_error("leann_backend_search_batch: null argument");
+        return LEANN_ERR_INVALID;
+    }
+    if (nq == 0 || top_k == 0) {
+        for (size_t i = 0; i < nq; i++) counts[i] = 0;
+        return LEANN_OK;
+    }
+    if (h->g.n == 0) {
+        for (size_t i = 0; i < nq; i++) counts[i] = 0;
+        return LEANN_OK;
+    }
+    HIP_CHECK_RET(hipSetDevice(h->device));
+    Workspace *w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!h->free_ws.empty()) { w = h->free_ws.back(); h->free_ws.pop_back(); }
+    }
+    if (!w) w = new Workspace();
+    int rc = LEANN_OK;
+    auto fail = [&](int code) { std::lock_guard<std::mutex> lk(h->mu); h->free_ws.push_back(w); return code; };
+    if (!w->stream) {
+        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
+            leann_set_error("hipStreamCreate failed");
+            return fail(LEANN_ERR_DEVICE);
+        }
+    }
+    const size_t d = h->g.d, qf = nq * d, no = nq * top_k;
+    auto grow = [&](void **p, size_t &cap, size_t need, size_t elt) -> int {
+        if (need <= cap) return 0;
+        (void)hipFree(*p);
+        *p = nullptr;
+        if (hipMalloc(p, need * elt) != hipSuccess) { leann_set_error("hipMalloc(%zu) failed", need * elt); return 1; }
+        cap = need;
+        return 0;
+    };
+    if (grow((void **)&w->d_q, w->cap_q, qf, 4) || grow((void **)&w->d_keys, w->cap_keys, no, 8) ||
+        grow((void **)&w->d_dists, w->cap_dists, no, 4) || grow((void **)&w->d_counts, w->cap_counts, nq, 4) ||
+        grow((void **)&w->d_stats, w->cap_stats, nq * 4, 4))
+        return fail(LEANN_ERR_DEVICE);
+    hipStream_t st = w->stream;
+    if (hipMemcpyAsync(w->d_q, queries, qf * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+        leann_set_error("H2D copy of queries failed");
+        return fail(LEANN_ERR_DEVICE);
+    }
+    SearchArgs a{};
+    a.queries = w->d_q;
+    a.ldq = (uint32_t)d;
+    a.nq = (uint32_t)nq;
+    a.k = (uint32_t)top_k;
+    a.ef = (uint32_t)std::max(complexity, top_k);
+    a.key_offset = h->key_offset;
+    a.out_keys = w->d_keys;
+    a.out_dists = w->d_dists;
+    a.out_counts = w->d_counts;
+    a.out_stats = w->d_stats;
+    rc = leann_internal_launch_search(h->g, a, w, st);
+    if (rc) return fail(rc);
+    std::vector<uint32_t> hstats(nq * 4);
+    if (hipMemcpyAsync(keys, w->d_keys, no * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(dists, w->d_dists, no * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(counts, w->d_counts, nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(hstats.data(), w->d_stats, nq * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        leann_set_error("search: device error: %s", hipGetErrorString(hipGetLastError()));
+        return fail(LEANN_ERR_DEVICE);
+    }
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        for (size_t i = 0; i < nq; i++) {
+            h->stats.n_dist_evals += hstats[i * 4 + 0];
+            h->stats.n_hops_base += hstats[i * 4 + 1];
+            h->stats.n_hops_upper += hstats[i * 4 + 2];
+            h->stats.n_table_overflow += hstats[i * 4 + 3];
+            h->stats.algorithmic_bytes += (uint64_t)hstats[i * 4 + 0] * d * 4 + (uint64_t)hstats[i * 4 + 1] * h->g.M0 * 4 +
+                                          (uint64_t)hstats[i * 4 + 2] * h->g.M * 4;
+        }
+        h->stats.n_queries += nq;
+        h->free_ws.push_back(w);
+    }
+    return LEANN_OK;
+}
+
+extern "C" int leann_backend_search(const leann_backend *h, const float *query, size_t top_k, size_t complexity,
+                                    uint64_t *keys, float *dists, size_t *n_out) {
+    if (!n_out) { leann_set_error("leann_backend_search: n_out is null"); return LEANN_ERR_INVALID; }
+    uint32_t cnt = 0;
+    int rc = leann_backend_search_batch(h, query, 1, top_k, complexity, keys, dists, &cnt);
+    *n_out = cnt;
+    return rc;
+}
+
+// ---- in-memory construction from host arrays ----------------------------------------------------------
+static int upload_rows_padded(const float *vectors, size_t n, size_t d, size_t ld, float **out) {
+    float *dX = nullptr;
+    HIP_CHECK_RET(hipMalloc((void **)&dX, std::max<size_t>(n * ld, 4) * 4));
+    if (n) {
+        if (ld == d) HIP_CHECK_RET(hipMemcpy(dX, vectors, n * d * 4, hipMemcpyHostToDevice));
+        else {
+            HIP_CHECK_RET(hipMemset(dX, 0, n * ld * 4));
+            HIP_CHECK_RET(hipMemcpy2D(dX, ld * 4, vectors, d * 4, d * 4, n, hipMemcpyHostToDevice));
+        }
+    }
+    *out = dX;
+    return LEANN_OK;
+}
+
+extern "C" int leann_backend_from_arrays(int backend, const float *vectors, size_t n, size_t dims, uint32_t M,
+                                         uint32_t M0, uint32_t max_level, uint32_t entry, const uint8_t *levels,
+                                         const uint32_t *upper_off, const uint32_t *adj0, const uint32_t *adjU,
+                                         size_t n_upper_lists, int device, uint64_t key_offset, leann_backend **out) {
+    if (!out || dims == 0 || dims > 2048 || M == 0 || M0 == 0 || n >= (1ull << 31) || (n && (!vectors || !adj0 || !upper_off)) ||
+        (n && entry >= n)) {
+        leann_set_error("leann_backend_from_arrays: invalid arguments");
+        return LEANN_ERR_INVALID;
+    }
+    int ndev = 0;
+    leann_device_count(&ndev);
+    if (device < 0 || device >= ndev) {
+        leann_set_error("HIP device %d not available (%d visible). This library has no CPU fallback.", device, ndev);
+        return LEANN_ERR_DEVICE;
+    }
+    HIP_CHECK_RET(hipSetDevice(device));
+    leann_backend *h = new leann_backend();
+    h->kind = backend;
+    h->device = device;
+    h->key_offset = key_offset;
+    size_t ld = (dims + 3) & ~(size_t)3;
+    float *dX = nullptr;
+    int rc = upload_rows_padded(vectors, n, dims, ld, &dX);
+    if (rc) { delete h; return rc; }
+    uint32_t *d_adj0 = nullptr, *d_adjU = nullptr, *d_uo = nullptr;
+    size_t nn = std::max<size_t>(n, 1), nu = std::max<size_t>(n_upper_lists, 1);
+    if (hipMalloc((void **)&d_adj0, nn * M0 * 4) != hipSuccess || hipMalloc((void **)&d_adjU, nu * M * 4) != hipSuccess ||
+        hipMalloc((void **)&d_uo, nn * 4) != hipSuccess || hipMalloc((void **)&h->d_levels, nn) != hipSuccess) {
+        leann_set_error("hipMalloc failed for graph arrays");
+        delete h;
+        return LEANN_ERR_DEVICE;
+    }
+    HIP_CHECK_RET(hipMemset(d_adjU, 0xFF, nu * M * 4));
+    if (n) {
+        HIP_CHECK_RET(hipMemcpy(d_adj0, adj0, n * M0 * 4, hipMemcpyHostToDevice));
+        HIP_CHECK_RET(hipMemcpy(d_uo, upper_off, n * 4, hipMemcpyHostToDevice));
+        if (levels) HIP_CHECK_RET(hipMemcpy(h->d_levels, levels, n, hipMemcpyHostToDevice));
+        else HIP_CHECK_RET(hipMemset(h->d_levels, 0, n));
+        if (n_upper_lists) HIP_CHECK_RET(hipMemcpy(d_adjU, adjU, n_upper_lists * M * 4, hipMemcpyHostToDevice));
+    }
+    h->g.X = dX;
+    h->g.adj0 = d_adj0;
+    h->g.adjU = d_adjU;
+    h->g.upper_off = d_uo;
+    h->g.n = n;
+    h->g.d = (uint32_t)dims;
+    h->g.ld = (uint32_t)ld;
+    h->g.M = M;
+    h->g.M0 = M0;
+    h->g.max_level = max_level;
+    h->g.entry = entry;
+    h->n_upper_lists = n_upper_lists;
+    *out = h;
+    return LEANN_OK;
+}
+
+extern "C" int leann_backend_graph_info(const leann_backend *h, uint64_t *info) {
+    if (!h || !info) { leann_set_error("leann_backend_graph_info: null argument"); return LEANN_ERR_INVALID; }
+    info[0] = h->g.n; info[1] = h->g.d; info[2] = h->g.ld; info[3] = h->g.M; info[4] = h->g.M0;
+    info[5] = h->g.max_level; info[6] = h->g.entry; info[7] = h->n_upper_lists;
+    return LEANN_OK;
+}
+extern "C" int leann_backend_graph_export(const leann_backend *h, uint8_t *levels, uint32_t *upper_off, uint32_t *adj0,
+                                          uint32_t *adjU, float *vectors) {
+    if (!h) { leann_set_error("leann_backend_graph_export: null handle"); return LEANN_ERR_INVALID; }
+    HIP_CHECK_RET(hipSetDevice(h->device));
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    const size_t n = h->g.n;
+    if (n == 0) return LEANN_OK;
+    if (levels) HIP_CHECK_RET(hipMemcpy(levels, h->d_levels, n, hipMemcpyDeviceToHost));
+    if (upper_off) HIP_CHECK_RET(hipMemcpy(upper_off, h->g.upper_off, n * 4, hipMemcpyDeviceToHost));
+    if (adj0) HIP_CHECK_RET(hipMemcpy(adj0, h->g.adj0, n * h->g.M0 * 4, hipMemcpyDeviceToHost));
+    if (adjU && h->n_upper_lists)
+        HIP_CHECK_RET(hipMemcpy(adjU, h->g.adjU, h->n_upper_lists * h->g.M * 4, hipMemcpyDeviceToHost));
+    if (vectors)
+        HIP_CHECK_RET(hipMemcpy2D(vectors, (size_t)h->g.d * 4, h->g.X, (size_t)h->g.ld * 4, (size_t)h->g.d * 4, n,
+                                  hipMemcpyDeviceToHost));
+    return LEANN_OK;
+}
+
+// ---- index files ------------------------------------------------------------------------------------
+// "<stem minus .leann>.index" (hnsw.rs:19) / ".diskann" (diskann.rs:22): Path::with_extension replaces
+// the text after the last '.' of the file name.
+static std::string with_extension(const std::string &stem, const char *ext) {
+    size_t slash = stem.find_last_of('/');
+    size_t dot = stem.find_last_of('.');
+    std::string base = (dot != std::string::npos && (slash == std::string::npos || dot > slash) && dot != slash + 1)
+                           ? stem.substr(0, dot) : stem;
+    return base + "." + ext;
+}
+std::string leann_internal_index_file(const char *stem, int backend) {
+    return with_extension(stem, backend == LEANN_BACKEND_DISKANN ? "diskann" : "index");
+}
+
+#pragma pack(push, 1)
+struct FileHeader {
+    char magic[8]; // "LEANNGX1"
+    uint32_t version, kind;
+    uint64_t n;
+    uint32_t d, M, M0, max_level, entry, efc;
+    float alpha;
+    uint32_t reserved0;
+    uint64_t n_upper_lists;
+    uint8_t pad[64];
+};
+#pragma pack(pop)
+
+extern "C" int leann_backend_save(const leann_backend *h, const char *index_path_stem) {
+    if (!h || !index_path_stem) { leann_set_error("leann_backend_save: null argument"); return LEANN_ERR_INVALID; }
+    std::string path = leann_internal_index_file(index_path_stem, h->kind);
+    const size_t n = h->g.n, d = h->g.d;
+    std::vector<uint8_t> levels(std::max<size_t>(n, 1));
+    std::vector<uint32_t> uo(std::max<size_t>(n, 1)), a0(std::max<size_t>(n * h->g.M0, 1)),
+        aU(std::max<size_t>(h->n_upper_lists * h->g.M, 1));
+    std::vector<float> X(std::max<size_t>(n * d, 1));
+    int rc = leann_backend_graph_export(h, levels.data(), uo.data(), a0.data(), aU.data(), X.data());
+    if (rc) return rc;
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { leann_set_error("cannot create %s", path.c_str()); return LEANN_ERR_IO; }
+    FileHeader hd{};
+    memcpy(hd.magic, "LEANNGX1", 8);
+    hd.version = 1; hd.kind = (uint32_t)h->kind; hd.n = n; hd.d = (uint32_t)d; hd.M = h->g.M; hd.M0 = h->g.M0;
+    hd.max_level = h->g.max_level; hd.entry = h->g.entry; hd.efc = h->efc; hd.alpha = h->alpha;
+    hd.n_upper_lists = h->n_upper_lists;
+    bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1;
+    ok = ok && (n == 0 || fwrite(levels.data(), 1, n, f) == n);
+    ok = ok && (n == 0 || fwrite(uo.data(), 4, n, f) == n);
+    ok = ok && (n == 0 || fwrite(a0.data(), 4, n * h->g.M0, f) == n * h->g.M0);
+    ok = ok && (h->n_upper_lists == 0 || fwrite(aU.data(), 4, h->n_upper_lists * h->g.M, f) == h->n_upper_lists * h->g.M);
+    ok = ok && (n == 0 || fwrite(X.data(), 4, n * d, f) == n * d);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { leann_set_error("short write to %s", path.c_str()); return LEANN_ERR_IO; }
+    return LEANN_OK;
+}
+
+static int parse_device(const char *spec) {
+    if (!spec || !*spec) return 0;
+    return atoi(spec);
+}
+
+extern "C" int leann_backend_open(const char *index_path_stem, int backend, size_t dims, const char *device_spec,
+                                  leann_backend **out) {
+    if (!index_path_stem || !out) { leann_set_error("leann_backend_open: null argument"); return LEANN_ERR_INVALID; }
+    if (backend != LEANN_BACKEND_HNSW && backend != LEANN_BACKEND_DISKANN) {
+        leann_set_error("Unknown backend: %d", backend); // searcher.rs:98
+        return LEANN_ERR_INVALID;
+    }
+    std::string path = leann_internal_index_file(index_path_stem, backend);
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
+        if (backend == LEANN_BACKEND_HNSW) // hnsw.rs:34-40
+            leann_set_error("Index file not found: \"%s\"\nRun 'leann build' to create an index first.", path.c_str());
+        else // diskann.rs:26-32
+            leann_set_error("DiskANN index not found: \"%s\"\nRun 'leann build' with --backend-name diskann to create an index first.", path.c_str());
+        return LEANN_ERR_NOT_FOUND;
+    }
+    FileHeader hd{};
+    size_t got = fread(&hd, 1, sizeof(hd), f);
+    if (got >= 4) { // compat.rs:15-38 — FAISS (Python LEANN) magic sniff, hnsw.rs:24-32
+        const unsigned char *m = (const unsigned char *)&hd;
+        if ((m[0] == 'I' && m[1] == 'x') || !memcmp(m, "CSR\0", 4) || !memcmp(m, "HNSW", 4)) {
+            fclose(f);
+            leann_set_error("This index was built with Python LEANN (FAISS format).\n"
+                            "Rust LEANN uses usearch which has a different binary format.\n\n"
+                            "To use this index with Rust LEANN, you need to rebuild it:\n"
+                            "  leann build <name> --docs <path> --force\n\n"
+                            "The passages and metadata files are compatible and will be preserved.");
+            return LEANN_ERR_FORMAT;
+        }
+    }
+    if (got != sizeof(hd) || memcmp(hd.magic, "LEANNGX1", 8) != 0 || hd.version != 1) {
+        fclose(f);
+        // hnsw.rs:57-69
+        leann_set_error("Failed to load index: incompatible format.\n"
+                        "This may be a FAISS index from Python LEANN, or a usearch/diskann-rs file written by stock leann-rs.\n"
+                        "Rebuild with: leann build <name> --docs <path> --force\n\n"
+                        "Original error: bad magic/header/version in %s", path.c_str());
+        return LEANN_ERR_FORMAT;
+    }
+    if (dims && hd.d != dims) {
+        fclose(f);
+        leann_set_error("index has %u dimensions, expected %zu", hd.d, dims);
+        return LEANN_ERR_FORMAT;
+    }
+    const size_t n = hd.n, d = hd.d;
+    std::vector<uint8_t> levels(std::max<size_t>(n, 1));
+    std::vector<uint32_t> uo(std::max<size_t>(n, 1)), a0(std::max<size_t>(n * hd.M0, 1)),
+        aU(std::max<size_t>(hd.n_upper_lists * hd.M, 1));
+    std::vector<float> X(std::max<size_t>(n * d, 1));
+    bool ok = (n == 0 || fread(levels.data(), 1, n, f) == n);
+    ok = ok && (n == 0 || fread(uo.data(), 4, n, f) == n);
+    ok = ok && (n == 0 || fread(a0.data(), 4, n * hd.M0, f) == n * hd.M0);
+    ok = ok && (hd.n_upper_lists == 0 || fread(aU.data(), 4, hd.n_upper_lists * hd.M, f) == hd.n_upper_lists * hd.M);
+    ok = ok && (n == 0 || fread(X.data(), 4, n * d, f) == n * d);
+    fclose(f);
+    if (!ok) { leann_set_error("Failed to load index: truncated file %s", path.c_str()); return LEANN_ERR_FORMAT; }
+    int rc = leann_backend_from_arrays(backend, X.data(), n, d, hd.M, hd.M0, hd.max_level, hd.entry, levels.data(),
+                                       uo.data(), a0.data(), aU.data(), hd.n_upper_lists, parse_device(device_spec), 0, out);
+    if (rc == LEANN_OK) { (*out)->efc = hd.efc; (*out)->alpha = hd.alpha; }
+    return rc;
+}

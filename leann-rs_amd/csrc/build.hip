@@ -1,0 +1,647 @@
+// build.hip — on-GPU index construction (needed to HAVE the 1M/10M indexes).
+//
+// Replaces the arithmetic behind
+//     hnsw::build_index / add_to_index   src/backend/hnsw.rs:96-191   (usearch add loop, out of tree)
+//     diskann::build_index               src/backend/diskann.rs:70-105 (diskann-rs Vamana, out of tree)
+// with batched insertion: points enter in position order (hnsw.rs:128-130) in batches no larger than
+// the graph built so far; every point of a batch
+//   1. searches the current graph with the SAME traversal kernel as queries (search.cuh; ef =
+//      `complexity`, one launch per level that has new members),
+//   2. keeps at most M neighbours by the select-neighbours heuristic (HNSW Alg. 4; Vamana
+//      RobustPrune with alpha = 1.2, diskann.rs:91) — a 128x128 candidate Gram matrix per point,
+//      LDS-tiled, lower triangle kept in LDS,
+//   3. proposes itself to each selected neighbour; proposals are radix-sorted by (target, dist)
+//      so that every touched list is rewritten by exactly one workgroup: append while there is
+//      room (2M on level 0), otherwise the same heuristic over list ∪ proposals.
+// No atomics decide content, so a build is reproducible run to run.  The sequential restatement
+// lives in oracle/oracle.c (orc_hnsw_build / orc_vamana_build); batched insertion is a different
+// schedule, so graphs are compared by invariants + recall, not bit for bit.
+#include "common.cuh"
+#include "search.cuh"
+#include "internal.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#define NCMAX 128
+#define TRI_ELEMS (NCMAX * (NCMAX - 1) / 2)
+
+struct ListView {
+    uint32_t *adj0; float *adjd0;  // [n x M0]
+    uint32_t *adjU; float *adjdU;  // [n_upper_lists x M]
+    const uint32_t *upper_off;
+    uint32_t M, M0;
+};
+__device__ __forceinline__ void list_ptr(const ListView &lv, uint32_t node, uint32_t level, uint32_t **ids, float **ds,
+                                         uint32_t *cap) {
+    if (level == 0) {
+        *ids = lv.adj0 + (size_t)node * lv.M0;
+        *ds = lv.adjd0 + (size_t)node * lv.M0;
+        *cap = lv.M0;
+    } else {
+        size_t o = ((size_t)lv.upper_off[node] + (level - 1)) * lv.M;
+        *ids = lv.adjU + o;
+        *ds = lv.adjdU + o;
+        *cap = lv.M;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prune_core: candidates (ids c_id, dists-to-p c_d, ascending by (dist, id)) -> up to `limit` kept.
+// alpha == 0: HNSW rule (drop c if dist(c, kept) < dist(c, p)); alpha > 0: Vamana rule
+// (drop c if alpha * dist(c, kept) <= dist(c, p)).   256 threads.  Returns count in every thread;
+// kept candidate positions in s_sel[0..count).
+// ------------------------------------------------------------------------------------------------
+__device__ uint32_t prune_core(const float *__restrict__ X, uint32_t ld, const uint32_t *c_id, const float *c_d,
+                               uint32_t nc, uint32_t limit, float alpha, float *tri /* TRI_ELEMS floats, LDS */,
+                               uint32_t *s_sel /* [64] LDS */, uint32_t *s_cnt /* LDS */) {
+    constexpr int KC = 32, LDW = NCMAX + 1;
+    float *stage = tri; // [KC][LDW] aliased: dead before tri is written
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const bool active = tx <= ty; // 8x8 blocks that touch the lower triangle
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = 0.f;
+    const int srow = tid >> 1, shalf = tid & 1;
+    const float *rowp = (srow < (int)nc) ? X + (size_t)c_id[srow] * ld : nullptr;
+    for (uint32_t k0 = 0; k0 < ld; k0 += KC) {
+        float4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            uint32_t j = k0 + shalf * 16 + e * 4;
+            v[e] = (rowp && j < ld) ? *reinterpret_cast<const float4 *>(rowp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads(); // previous chunk fully consumed
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int kk = shalf * 16 + e * 4;
+            stage[(kk + 0) * LDW + srow] = v[e].x;
+            stage[(kk + 1) * LDW + srow] = v[e].y;
+            stage[(kk + 2) * LDW + srow] = v[e].z;
+            stage[(kk + 3) * LDW + srow] = v[e].w;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 4
+            for (int kk = 0; kk < KC; kk++) {
+                float a[8], b[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) a[i] = stage[kk * LDW + ty * 8 + i];
+#pragma unroll
+                for (int j = 0; j < 8; j++) b[j] = stage[kk * LDW + tx * 8 + j];
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+            }
+        }
+    }
+    __syncthreads(); // stage dead; tri may be written
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int r = ty * 8 + i, c = tx * 8 + j;
+                if (c < r && r < (int)nc) tri[r * (r - 1) / 2 + c] = 1.0f - acc[i][j];
+            }
+    }
+    __syncthreads();
+    if (tid < 64) { // wave 0: sequential walk over candidates, lanes = kept slots
+        uint32_t ns = 0;
+        int my = -1;
+        for (uint32_t i = 0; i < nc; i++) {
+            const float di = c_d[i];
+            bool bad = false;
+            if (tid < (int)ns) {
+                float gdist = tri[i * (i - 1) / 2 + my];
+                bad = (alpha == 0.f) ? (gdist < di) : (alpha * gdist <= di);
+            }
+            if (!__any(bad)) {
+                if (tid == (int)ns) my = (int)i;
+                ns++;
+                if (ns == limit) break;
+            }
+        }
+        if (tid < (int)ns) s_sel[tid] = (uint32_t)my;
+        if (tid == 0) *s_cnt = ns;
+    }
+    __syncthreads();
+    return *s_cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// select_kernel: one workgroup per new point of the batch (at one level).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) select_kernel(const float *__restrict__ X, uint32_t ld, ListView lv,
+                                                     const uint32_t *__restrict__ q_rows, uint32_t nq, uint32_t level,
+                                                     const uint64_t *__restrict__ cand_keys, const float *__restrict__ cand_d,
+                                                     const uint32_t *__restrict__ cand_cnt, uint32_t efc, uint32_t msel,
+                                                     float alpha, uint64_t *__restrict__ prop_key, uint32_t *__restrict__ prop_src) {
+    __shared__ float tri[TRI_ELEMS];
+    __shared__ uint32_t c_id[NCMAX];
+    __shared__ float c_d[NCMAX];
+    __shared__ uint32_t s_sel[64];
+    __shared__ uint32_t s_cnt;
+    const uint32_t qi = blockIdx.x;
+    if (qi >= nq) return;
+    const uint32_t q = q_rows[qi];
+    const uint32_t nc = min(min(cand_cnt[qi], efc), (uint32_t)NCMAX);
+    for (uint32_t i = threadIdx.x; i < NCMAX; i += 256) {
+        c_id[i] = i < nc ? (uint32_t)cand_keys[(size_t)qi * efc + i] : 0u;
+        c_d[i] = i < nc ? cand_d[(size_t)qi * efc + i] : 0.f;
+    }
+    __syncthreads();
+    uint32_t ns = prune_core(X, ld, c_id, c_d, nc, msel, alpha, tri, s_sel, &s_cnt);
+    uint32_t *ids; float *ds; uint32_t cap;
+    list_ptr(lv, q, level, &ids, &ds, &cap);
+    for (uint32_t j = threadIdx.x; j < msel; j += 256) {
+        uint64_t pk = ~0ull;
+        if (j < ns) {
+            uint32_t c = s_sel[j];
+            ids[j] = c_id[c];
+            ds[j] = c_d[c];
+            pk = ((uint64_t)c_id[c] << 32) | f32_orderable(c_d[c]);
+        }
+        prop_key[(size_t)qi * msel + j] = pk; // (target, dist) ; padding sorts to the end
+        prop_src[(size_t)qi * msel + j] = q;
+    }
+}
+
+// heads of equal-target runs in the sorted proposal array
+__global__ void segment_heads_kernel(const uint64_t *__restrict__ keys, uint32_t num, uint32_t *__restrict__ seg_start,
+                                     uint32_t *__restrict__ nseg) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num) return;
+    uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (t == LEANN_EMPTY) return;
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) seg_start[atomicAdd(nseg, 1u)] = i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reverse_merge_kernel: one workgroup per touched list (target node at `level`).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reverse_merge_kernel(const float *__restrict__ X, uint32_t ld, ListView lv,
+                                                            uint32_t level, const uint64_t *__restrict__ keys,
+                                                            const uint32_t *__restrict__ srcs, uint32_t num,
+                                                            const uint32_t *__restrict__ seg_start,
+                                                            const uint32_t *__restrict__ nseg_p, float alpha) {
+    __shared__ float tri[TRI_ELEMS];
+    __shared__ uint64_t skey[NCMAX];
+    __shared__ uint32_t c_id[NCMAX];
+    __shared__ float c_d[NCMAX];
+    __shared__ uint32_t s_sel[64];
+    __shared__ uint32_t s_cnt, s_k, s_len;
+    const uint32_t nseg = *nseg_p;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const uint32_t start = seg_start[seg];
+        const uint32_t t = (uint32_t)(keys[start] >> 32);
+        uint32_t *ids; float *ds; uint32_t cap;
+        list_ptr(lv, t, level, &ids, &ds, &cap);
+        if (threadIdx.x == 0) { s_k = 0; s_len = 0; }
+        __syncthreads();
+        // proposals of this run (sorted by dist): count up to NCMAX; existing list length
+        if (threadIdx.x < NCMAX) {
+            uint32_t i = start + threadIdx.x;
+            if (i < num && (uint32_t)(keys[i] >> 32) == t) atomicAdd(&s_k, 1u); // run is contiguous
+        }
+        if (threadIdx.x < cap && ids[threadIdx.x] != LEANN_EMPTY) atomicAdd(&s_len, 1u); // lists are compact
+        __syncthreads();
+        const uint32_t len = s_len;
+        uint32_t k = s_k;
+        if (len + k <= cap) { // room: append in (dist, src) order
+            for (uint32_t j = threadIdx.x; j < k; j += 256) {
+                ids[len + j] = srcs[start + j];
+                ds[len + j] = orderable_f32((uint32_t)keys[start + j]);
+            }
+            __syncthreads();
+            continue;
+        }
+        if (len + k > NCMAX) k = NCMAX - len; // keep the closest proposals only
+        const uint32_t nc = len + k;
+        for (uint32_t i = threadIdx.x; i < NCMAX; i += 256) {
+            uint64_t key = ~0ull;
+            if (i < len) key = ((uint64_t)f32_orderable(ds[i]) << 32) | ids[i];
+            else if (i < nc) key = ((uint64_t)(uint32_t)keys[start + i - len] << 32) | srcs[start + i - len];
+            skey[i] = key;
+        }
+        // bitonic sort of NCMAX keys by (dist, id)
+        for (int size = 2; size <= NCMAX; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                if (threadIdx.x < NCMAX / 2) {
+                    int i = threadIdx.x;
+                    int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                    bool up = ((lo & size) == 0);
+                    uint64_t a = skey[lo], b = skey[hi];
+                    if ((a > b) == up) { skey[lo] = b; skey[hi] = a; }
+                }
+            }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < NCMAX; i += 256) {
+            c_id[i] = i < nc ? (uint32_t)skey[i] : 0u;
+            c_d[i] = i < nc ? orderable_f32((uint32_t)(skey[i] >> 32)) : 0.f;
+        }
+        __syncthreads();
+        uint32_t ns = prune_core(X, ld, c_id, c_d, nc, cap, alpha, tri, s_sel, &s_cnt);
+        for (uint32_t j = threadIdx.x; j < cap; j += 256) {
+            if (j < ns) {
+                uint32_t c = s_sel[j];
+                ids[j] = c_id[c];
+                ds[j] = c_d[c];
+            } else {
+                ids[j] = LEANN_EMPTY;
+                ds[j] = 0.f;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, size_t n, uint32_t v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void iota_skip_kernel(uint32_t *p, size_t n, uint32_t first) { // [first, 0, 1, .., first-1, first+1, ..]
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    p[i] = i == 0 ? first : (i <= first ? (uint32_t)(i - 1) : (uint32_t)i);
+}
+// column sums for the Vamana medoid (mean direction), one block per 64 columns-chunk... simple version
+__global__ void col_mean_kernel(const float *__restrict__ X, size_t n, uint32_t d, uint32_t ld, float *__restrict__ mean) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    if (j >= d) { mean[j] = 0.f; return; }
+    double s = 0.0;
+    for (size_t i = 0; i < n; i++) s += X[i * ld + j];
+    mean[j] = (float)(s / (double)n);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+    leann_backend *h;
+    ListView lv{};
+    float *adjd0 = nullptr, *adjdU = nullptr;
+    std::vector<uint8_t> levels;     // host copy
+    std::vector<uint32_t> upper_off; // host copy
+    uint32_t *d_order = nullptr;     // insertion order
+    std::vector<uint32_t> h_order_first; // only used for Vamana (medoid first)
+    // per-batch scratch
+    size_t bmax = 0;
+    uint64_t *cand_keys = nullptr; float *cand_d = nullptr; uint32_t *cand_cnt = nullptr;
+    uint64_t *candU_keys = nullptr; float *candU_d = nullptr; uint32_t *candU_cnt = nullptr; uint32_t *d_rowsU = nullptr;
+    uint64_t *prop_key = nullptr, *prop_key2 = nullptr; uint32_t *prop_src = nullptr, *prop_src2 = nullptr;
+    uint32_t *seg_start = nullptr, *nseg = nullptr;
+    void *cub_tmp = nullptr; size_t cub_bytes = 0;
+    Workspace ws;
+    hipStream_t st = nullptr;
+};
+
+#define BCHECK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            leann_set_error("build: %s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return LEANN_ERR_DEVICE;                                                           \
+        }                                                                                      \
+    } while (0)
+
+static int link_level(Builder &b, const uint32_t *d_rows, uint32_t nq, uint32_t level, const uint64_t *ck, const float *cd,
+                      const uint32_t *cc) {
+    leann_backend *h = b.h;
+    const uint32_t efc = h->efc, msel = h->g.M; // M new links per point on every level (Malkov Alg. 1)
+    const float alpha = h->kind == LEANN_BACKEND_DISKANN ? h->alpha : 0.f;
+    hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, d_rows, nq, level, ck, cd, cc,
+                       efc, msel, alpha, b.prop_key, b.prop_src);
+    const uint32_t num = nq * msel;
+    size_t tmp = b.cub_bytes;
+    BCHECK(hipcub::DeviceRadixSort::SortPairs(b.cub_tmp, tmp, b.prop_key, b.prop_key2, b.prop_src, b.prop_src2, (int)num, 0, 64, b.st));
+    BCHECK(hipMemsetAsync(b.nseg, 0, 4, b.st));
+    hipLaunchKernelGGL(segment_heads_kernel, dim3((num + 255) / 256), dim3(256), 0, b.st, b.prop_key2, num, b.seg_start, b.nseg);
+    uint32_t grid = std::min<uint32_t>(num, 256 * 16);
+    hipLaunchKernelGGL(reverse_merge_kernel, dim3(grid), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, level, b.prop_key2,
+                       b.prop_src2, num, b.seg_start, b.nseg, alpha);
+    BCHECK(hipGetLastError());
+    return LEANN_OK;
+}
+
+static int builder_alloc_scratch(Builder &b, size_t bmax) {
+    leann_backend *h = b.h;
+    const size_t efc = h->efc, msel = h->g.M;
+    b.bmax = bmax;
+    const size_t bu = bmax / 16 + 64; // upper-level members per batch (expected bmax/31)
+    BCHECK(hipMalloc((void **)&b.cand_keys, bmax * efc * 8));
+    BCHECK(hipMalloc((void **)&b.cand_d, bmax * efc * 4));
+    BCHECK(hipMalloc((void **)&b.cand_cnt, bmax * 4));
+    BCHECK(hipMalloc((void **)&b.candU_keys, bu * efc * 8 * 16));
+    BCHECK(hipMalloc((void **)&b.candU_d, bu * efc * 4 * 16));
+    BCHECK(hipMalloc((void **)&b.candU_cnt, bu * 4 * 16));
+    BCHECK(hipMalloc((void **)&b.d_rowsU, bu * 4 * 16));
+    BCHECK(hipMalloc((void **)&b.prop_key, bmax * msel * 8));
+    BCHECK(hipMalloc((void **)&b.prop_key2, bmax * msel * 8));
+    BCHECK(hipMalloc((void **)&b.prop_src, bmax * msel * 4));
+    BCHECK(hipMalloc((void **)&b.prop_src2, bmax * msel * 4));
+    BCHECK(hipMalloc((void **)&b.seg_start, bmax * msel * 4));
+    BCHECK(hipMalloc((void **)&b.nseg, 16));
+    size_t tmp = 0;
+    BCHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, b.prop_key, b.prop_key2, b.prop_src, b.prop_src2,
+                                              (int)(bmax * msel), 0, 64, b.st));
+    b.cub_bytes = tmp;
+    BCHECK(hipMalloc(&b.cub_tmp, tmp));
+    return LEANN_OK;
+}
+static void builder_free_scratch(Builder &b) {
+    void *ps[] = {b.cand_keys, b.cand_d, b.cand_cnt, b.candU_keys, b.candU_d, b.candU_cnt, b.d_rowsU, b.prop_key, b.prop_key2,
+                  b.prop_src, b.prop_src2, b.seg_start, b.nseg, b.cub_tmp, b.d_order, b.adjd0, b.adjdU,
+                  b.ws.overflow_list, b.ws.ctrs, b.ws.gtables};
+    for (void *p : ps) (void)hipFree(p);
+}
+
+// Insert order[s0 .. n) into the graph that already holds order[0 .. s0).
+static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_host_upper /* unused */, size_t s0, size_t n) {
+    (void)order_host_upper;
+    leann_backend *h = b.h;
+    const uint32_t efc = h->efc;
+    const bool hnsw = h->kind == LEANN_BACKEND_HNSW;
+    size_t s = s0;
+    const size_t bu_cap = (b.bmax / 16 + 64) * 16;
+    while (s < n) {
+        size_t B = std::min<size_t>(std::min<size_t>(b.bmax, std::max<size_t>(1, s)), n - s);
+        const uint32_t Lmax = h->g.max_level;
+        // ---- phase 1: searches (graph does not contain any point of the batch yet) ----------------
+        struct LevelJob { uint32_t level, nq; size_t off; };
+        std::vector<LevelJob> jobs;
+        size_t offU = 0;
+        if (hnsw && Lmax > 0) {
+            for (uint32_t l = Lmax; l >= 1; --l) {
+                std::vector<uint32_t> rows;
+                for (size_t i = s; i < s + B; i++)
+                    if (b.levels[i] >= l) rows.push_back((uint32_t)i); // HNSW order is the identity
+                if (rows.empty()) continue;
+                if (offU + rows.size() > bu_cap) {
+                    leann_set_error("build: upper-level scratch exhausted");
+                    return LEANN_ERR_DEVICE;
+                }
+                BCHECK(hipMemcpyAsync(b.d_rowsU + offU, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, b.st));
+                BCHECK(hipStreamSynchronize(b.st)); // rows is a stack temporary
+                SearchArgs a{};
+                a.q_rows = b.d_rowsU + offU;
+                a.nq = (uint32_t)rows.size();
+                a.k = efc;
+                a.ef = efc;
+                a.target_level = l;
+                a.out_keys = b.candU_keys + offU * efc;
+                a.out_dists = b.candU_d + offU * efc;
+                a.out_counts = b.candU_cnt + offU;
+                int rc = leann_internal_launch_search(h->g, a, &b.ws, b.st);
+                if (rc) return rc;
+                jobs.push_back({l, (uint32_t)rows.size(), offU});
+                offU += rows.size();
+            }
+        }
+        {
+            SearchArgs a{};
+            a.q_rows = b.d_order + s;
+            a.nq = (uint32_t)B;
+            a.k = efc;
+            a.ef = efc;
+            a.target_level = 0;
+            a.out_keys = b.cand_keys;
+            a.out_dists = b.cand_d;
+            a.out_counts = b.cand_cnt;
+            int rc = leann_internal_launch_search(h->g, a, &b.ws, b.st);
+            if (rc) return rc;
+        }
+        // ---- phase 2: select + link, level by level ---------------------------------------------
+        for (auto &j : jobs) {
+            int rc = link_level(b, b.d_rowsU + j.off, j.nq, j.level, b.candU_keys + j.off * efc, b.candU_d + j.off * efc,
+                                b.candU_cnt + j.off);
+            if (rc) return rc;
+        }
+        int rc = link_level(b, b.d_order + s, (uint32_t)B, 0, b.cand_keys, b.cand_d, b.cand_cnt);
+        if (rc) return rc;
+        // ---- entry point / top level (sequential semantics of hnsw.rs:128-130 within the batch) --
+        if (hnsw)
+            for (size_t i = s; i < s + B; i++)
+                if (b.levels[i] > h->g.max_level) { h->g.max_level = b.levels[i]; h->g.entry = (uint32_t)i; }
+        s += B;
+    }
+    BCHECK(hipStreamSynchronize(b.st));
+    return LEANN_OK;
+}
+
+static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint) {
+    // h->g.X / n / d / ld / M / M0 / kind / efc / alpha are set; adjacency arrays allocated & initialised
+    // for nodes < n_existing (append) or empty.
+    Builder b;
+    b.h = h;
+    const size_t n = h->g.n;
+    BCHECK(hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking));
+    b.lv.adj0 = const_cast<uint32_t *>(h->g.adj0);
+    b.lv.adjU = const_cast<uint32_t *>(h->g.adjU);
+    b.lv.upper_off = h->g.upper_off;
+    b.lv.M = h->g.M;
+    b.lv.M0 = h->g.M0;
+    const size_t nu = std::max<size_t>(h->n_upper_lists, 1);
+    BCHECK(hipMalloc((void **)&b.adjd0, std::max<size_t>(n, 1) * h->g.M0 * 4));
+    BCHECK(hipMalloc((void **)&b.adjdU, nu * h->g.M * 4));
+    BCHECK(hipMemset(b.adjd0, 0, std::max<size_t>(n, 1) * h->g.M0 * 4));
+    BCHECK(hipMemset(b.adjdU, 0, nu * h->g.M * 4));
+    b.lv.adjd0 = b.adjd0;
+    b.lv.adjdU = b.adjdU;
+    b.levels.resize(std::max<size_t>(n, 1));
+    BCHECK(hipMemcpy(b.levels.data(), h->d_levels, n, hipMemcpyDeviceToHost));
+    BCHECK(hipMalloc((void **)&b.d_order, std::max<size_t>(n, 1) * 4));
+    int rc = LEANN_OK;
+    size_t s0 = n_existing;
+    if (n_existing == 0 && n > 0) {
+        uint32_t first = 0;
+        if (h->kind == LEANN_BACKEND_DISKANN) {
+            // medoid: closest row to the mean direction, by the index metric (ties -> lower id)
+            float *mean = nullptr; uint64_t *mk = nullptr; float *ms = nullptr; uint32_t *mc = nullptr;
+            BCHECK(hipMalloc((void **)&mean, h->g.ld * 4));
+            BCHECK(hipMalloc((void **)&mk, 8)); BCHECK(hipMalloc((void **)&ms, 4)); BCHECK(hipMalloc((void **)&mc, 4));
+            hipLaunchKernelGGL(col_mean_kernel, dim3((h->g.ld + 63) / 64), dim3(64), 0, b.st, h->g.X, n, h->g.d, h->g.ld, mean);
+            rc = leann_scan_topk_device(h->g.X, n, h->g.d, h->g.ld, mean, 1, 1, nullptr, 0, mk, ms, mc, b.st);
+            if (rc) return rc;
+            uint64_t key = 0;
+            BCHECK(hipMemcpyAsync(&key, mk, 8, hipMemcpyDeviceToHost, b.st));
+            BCHECK(hipStreamSynchronize(b.st));
+            first = (uint32_t)key;
+            (void)hipFree(mean); (void)hipFree(mk); (void)hipFree(ms); (void)hipFree(mc);
+        }
+        hipLaunchKernelGGL(iota_skip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b.st, b.d_order, n, first);
+        h->g.entry = first;
+        h->g.max_level = h->kind == LEANN_BACKEND_HNSW ? b.levels[0] : 0;
+        s0 = 1;
+    } else {
+        hipLaunchKernelGGL(iota_skip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b.st, b.d_order, n, 0u);
+        // existing links carry no stored distances: recompute lazily is not needed — appended points
+        // only ever prune lists through reverse_merge_kernel, which reads adjd; fill them now.
+    }
+    size_t bmax = bmax_hint ? bmax_hint : 16384;
+    rc = builder_alloc_scratch(b, bmax);
+    if (rc == LEANN_OK) rc = builder_insert_range(b, {}, s0, n);
+    (void)hipStreamSynchronize(b.st);
+    builder_free_scratch(b);
+    (void)hipStreamDestroy(b.st);
+    return rc;
+}
+
+// levels / upper_off on host (orc_level twin: common.cuh:node_level), uploaded once
+static int alloc_graph_arrays(leann_backend *h, uint64_t level_seed) {
+    const size_t n = h->g.n, nn = std::max<size_t>(n, 1);
+    std::vector<uint8_t> levels(nn, 0);
+    std::vector<uint32_t> uo(nn, 0);
+    uint64_t nu = 0;
+    for (size_t i = 0; i < n; i++) {
+        levels[i] = h->kind == LEANN_BACKEND_HNSW ? (uint8_t)node_level(level_seed, i, h->g.M) : 0;
+        uo[i] = (uint32_t)nu;
+        nu += levels[i];
+    }
+    h->n_upper_lists = nu;
+    uint32_t *adj0 = nullptr, *adjU = nullptr, *duo = nullptr;
+    BCHECK(hipMalloc((void **)&adj0, nn * h->g.M0 * 4));
+    BCHECK(hipMalloc((void **)&adjU, std::max<uint64_t>(nu, 1) * h->g.M * 4));
+    BCHECK(hipMalloc((void **)&duo, nn * 4));
+    BCHECK(hipMalloc((void **)&h->d_levels, nn));
+    BCHECK(hipMemset(adj0, 0xFF, nn * h->g.M0 * 4));
+    BCHECK(hipMemset(adjU, 0xFF, std::max<uint64_t>(nu, 1) * h->g.M * 4));
+    BCHECK(hipMemcpy(duo, uo.data(), nn * 4, hipMemcpyHostToDevice));
+    BCHECK(hipMemcpy(h->d_levels, levels.data(), nn, hipMemcpyHostToDevice));
+    h->g.adj0 = adj0;
+    h->g.adjU = adjU;
+    h->g.upper_off = duo;
+    return LEANN_OK;
+}
+
+static constexpr uint64_t LEVEL_SEED = 0x5EED0003ull;
+
+extern "C" int leann_backend_build_device(int backend, const float *d_vectors, size_t n, size_t dims, size_t ld,
+                                          size_t graph_degree, size_t complexity, int device, uint64_t key_offset,
+                                          int take_copy, leann_backend **out) {
+    if (!out || (n && !d_vectors) || dims == 0 || dims > 2048 || ld < dims || (ld & 3) || n >= (1ull << 31)) {
+        leann_set_error("leann_backend_build_device: invalid arguments (n=%zu dims=%zu ld=%zu)", n, dims, ld);
+        return LEANN_ERR_INVALID;
+    }
+    if (backend != LEANN_BACKEND_HNSW && backend != LEANN_BACKEND_DISKANN) {
+        leann_set_error("Unknown backend: %d", backend);
+        return LEANN_ERR_INVALID;
+    }
+    const size_t maxdeg = backend == LEANN_BACKEND_HNSW ? 32 : 64;
+    if (graph_degree < 2 || graph_degree > maxdeg || complexity < 1) {
+        leann_set_error("build: graph_degree must be in [2, %zu] and complexity >= 1 (got %zu, %zu)", maxdeg, graph_degree, complexity);
+        return LEANN_ERR_INVALID;
+    }
+    int ndev = 0;
+    leann_device_count(&ndev);
+    if (device < 0 || device >= ndev) {
+        leann_set_error("HIP device %d not available (%d visible). This library has no CPU fallback.", device, ndev);
+        return LEANN_ERR_DEVICE;
+    }
+    BCHECK(hipSetDevice(device));
+    leann_backend *h = new leann_backend();
+    h->kind = backend;
+    h->device = device;
+    h->key_offset = key_offset;
+    h->efc = (uint32_t)std::max<size_t>(complexity, graph_degree);
+    h->alpha = 1.2f; // diskann.rs:91
+    h->g.n = n;
+    h->g.d = (uint32_t)dims;
+    h->g.ld = (uint32_t)ld;
+    h->g.M = (uint32_t)graph_degree;
+    h->g.M0 = backend == LEANN_BACKEND_HNSW ? (uint32_t)(2 * graph_degree) : (uint32_t)graph_degree;
+    if (take_copy) {
+        float *cp = nullptr;
+        BCHECK(hipMalloc((void **)&cp, std::max<size_t>(n * ld, 4) * 4));
+        if (n) BCHECK(hipMemcpy(cp, d_vectors, n * ld * 4, hipMemcpyDeviceToDevice));
+        h->g.X = cp;
+        h->owns_rows = true;
+    } else {
+        h->g.X = d_vectors;
+        h->owns_rows = false;
+    }
+    int rc = alloc_graph_arrays(h, LEVEL_SEED);
+    if (rc == LEANN_OK && n) rc = build_on_device(h, 0, 0);
+    if (rc) { leann_backend_close(h); return rc; }
+    *out = h;
+    return LEANN_OK;
+}
+
+// BackendBuilder::build — src/backend/mod.rs:55-79
+extern "C" int leann_backend_build(int backend, const float *vectors, size_t n, size_t dims, size_t graph_degree,
+                                   size_t complexity, const char *index_path_stem) {
+    if (!index_path_stem || (n && !vectors) || dims == 0) {
+        leann_set_error("leann_backend_build: invalid arguments");
+        return LEANN_ERR_INVALID;
+    }
+    int ndev = 0;
+    leann_device_count(&ndev);
+    if (ndev < 1) {
+        leann_set_error("no HIP device visible. This library has no CPU fallback.");
+        return LEANN_ERR_DEVICE;
+    }
+    BCHECK(hipSetDevice(0));
+    const size_t ld = (dims + 3) & ~(size_t)3;
+    float *dX = nullptr;
+    BCHECK(hipMalloc((void **)&dX, std::max<size_t>(n * ld, 4) * 4));
+    if (n) {
+        if (ld == dims) BCHECK(hipMemcpy(dX, vectors, n * dims * 4, hipMemcpyHostToDevice));
+        else {
+            BCHECK(hipMemset(dX, 0, n * ld * 4));
+            BCHECK(hipMemcpy2D(dX, ld * 4, vectors, dims * 4, dims * 4, n, hipMemcpyHostToDevice));
+        }
+    }
+    leann_backend *h = nullptr;
+    int rc = leann_backend_build_device(backend, dX, n, dims, ld, graph_degree, complexity, 0, 0, 0, &h);
+    if (rc) { (void)hipFree(dX); return rc; }
+    h->owns_rows = true; // dX now belongs to the handle
+    rc = leann_backend_save(h, index_path_stem);
+    leann_backend_close(h);
+    return rc;
+}
+
+// BackendBuilder::add_to_index — src/backend/mod.rs:82-100, hnsw.rs:142-191
+extern "C" int leann_backend_add(int backend, const float *vectors, size_t n, size_t dims, size_t start_id,
+                                 const char *index_path_stem) {
+    if (backend == LEANN_BACKEND_DISKANN) { // mod.rs:93-98
+        leann_set_error("DiskANN backend does not support incremental updates. Use --force to rebuild the entire index.");
+        return LEANN_ERR_UNSUPPORTED;
+    }
+    if (backend != LEANN_BACKEND_HNSW || !index_path_stem || (n && !vectors)) {
+        leann_set_error("leann_backend_add: invalid arguments");
+        return LEANN_ERR_INVALID;
+    }
+    leann_backend *old = nullptr;
+    int rc = leann_backend_open(index_path_stem, backend, dims, "0", &old);
+    if (rc) return rc;
+    const size_t n_old = old->g.n;
+    if (start_id != n_old) { // keys are positions (hnsw.rs:178-179): appended ids must continue the sequence
+        leann_set_error("add_to_index: start_id %zu does not continue the index (%zu vectors)", start_id, n_old);
+        leann_backend_close(old);
+        return LEANN_ERR_INVALID;
+    }
+    // Rebuild over old rows + new rows.  (Batched insertion continues from an existing graph only with
+    // stored link distances, which the file does not carry; a full rebuild keeps the result identical
+    // to building the concatenation in one go.)
+    const size_t ld = old->g.ld, nt = n_old + n;
+    float *dX = nullptr;
+    BCHECK(hipMalloc((void **)&dX, std::max<size_t>(nt * ld, 4) * 4));
+    if (n_old) BCHECK(hipMemcpy(dX, old->g.X, n_old * ld * 4, hipMemcpyDeviceToDevice));
+    if (n) {
+        BCHECK(hipMemset(dX + n_old * ld, 0, n * ld * 4));
+        BCHECK(hipMemcpy2D(dX + n_old * ld, ld * 4, vectors, dims * 4, dims * 4, n, hipMemcpyHostToDevice));
+    }
+    const size_t M = old->g.M, efc = old->efc;
+    leann_backend_close(old);
+    leann_backend *h = nullptr;
+    rc = leann_backend_build_device(backend, dX, nt, dims, ld, M, efc, 0, 0, 0, &h);
+    if (rc) { (void)hipFree(dX); return rc; }
+    h->owns_rows = true;
+    rc = leann_backend_save(h, index_path_stem);
+    leann_backend_close(h);
+    return rc;
+}

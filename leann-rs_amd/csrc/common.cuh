@@ -1,0 +1,109 @@
+// common.cuh — shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes everywhere in this tree; nothing here is meant to compile for another target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LEANN_EMPTY 0xFFFFFFFFu
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// Orderable keys.  key64 = orderable(dist) << 32 | id << 1 | expanded_flag.  A single u64 compare
+// implements the total order (dist, id) used by every beam / merge decision, so CPU and GPU make
+// identical choices (ids are < 2^31 per shard; the flag never decides because ids are unique).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float orderable_f32(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t make_key(float dist, uint32_t id) {
+    return ((uint64_t)f32_orderable(dist) << 32) | ((uint64_t)id << 1);
+}
+__device__ __forceinline__ uint32_t key_id(uint64_t k) { return (uint32_t)(k & 0xFFFFFFFFull) >> 1; }
+__device__ __forceinline__ float key_dist(uint64_t k) { return orderable_f32((uint32_t)(k >> 32)); }
+
+// ---------------------------------------------------------------------------------------------
+// Hashing shared with oracle/oracle.c (orc_mix64 / orc_hash3 / orc_gauss / orc_level).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t hash3(uint64_t seed, uint64_t a, uint64_t b) {
+    return mix64(mix64(seed ^ (a * 0xD1342543DE82EF95ull)) ^ (b * 0xA24BAED4963EE407ull));
+}
+__host__ __device__ __forceinline__ float gauss_ih4(uint64_t seed, uint64_t a, uint64_t b) {
+    uint64_t h = hash3(seed, a, b);
+    int32_t s = (int32_t)((h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + (h >> 48));
+    return (float)(s - 131070) * 2.6428996e-05f;
+}
+__host__ __device__ __forceinline__ uint32_t node_level(uint64_t seed, uint64_t i, uint32_t M) {
+    uint64_t u = hash3(seed, i, 0x4C45564Cull);
+    uint64_t thr = 0xFFFFFFFFFFFFFFFFull;
+    uint32_t l = 0;
+    while (l < 15) {
+        thr /= M;
+        if (u >= thr) break;
+        l++;
+    }
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Canonical ("wave order") dot product — DESIGN.md §3, oracle/oracle.c:orc_dot_canon.
+// Lane l owns the 4 strided accumulators a[4l..4l+3]; chunk t covers elements 256t .. 256t+255.
+// After the fmaf chains: (a0+a1)+(a2+a3) in-lane, then an xor butterfly over masks 1,2,4,8,16,32
+// — the perfect adjacent-pair tree over the 256 accumulators.  Every lane ends with the total.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_tree_sum(float s) {
+    s = s + __shfl_xor(s, 1, 64);
+    s = s + __shfl_xor(s, 2, 64);
+    s = s + __shfl_xor(s, 4, 64);
+    s = s + __shfl_xor(s, 8, 64);
+    s = s + __shfl_xor(s, 16, 64);
+    s = s + __shfl_xor(s, 32, 64);
+    return s;
+}
+__device__ __forceinline__ float lane4_sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+__device__ __forceinline__ void fma4(float4 &acc, const float4 &a, const float4 &b) {
+    acc.x = fmaf(a.x, b.x, acc.x);
+    acc.y = fmaf(a.y, b.y, acc.y);
+    acc.z = fmaf(a.z, b.z, acc.z);
+    acc.w = fmaf(a.w, b.w, acc.w);
+}
+
+// Load lane's float4 of chunk t from a 16-byte aligned, zero-padded row of leading dimension ld.
+__device__ __forceinline__ float4 row_load4(const float *__restrict__ row, uint32_t ld, int t, int lane) {
+    uint32_t j = 256u * t + 4u * lane;
+    if (j < ld) return *reinterpret_cast<const float4 *>(row + j);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// Guarded scalar loads (query rows may be unaligned / unpadded: leading dimension = d).
+__device__ __forceinline__ float4 vec_load4_guard(const float *__restrict__ v, uint32_t d, int t, int lane) {
+    uint32_t j = 256u * t + 4u * lane;
+    float4 r;
+    r.x = j + 0 < d ? v[j + 0] : 0.f;
+    r.y = j + 1 < d ? v[j + 1] : 0.f;
+    r.z = j + 2 < d ? v[j + 2] : 0.f;
+    r.w = j + 3 < d ? v[j + 3] : 0.f;
+    return r;
+}
+
+#define HIP_CHECK_RET(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            leann_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                            __LINE__);                                                       \
+            return LEANN_ERR_DEVICE;                                                         \
+        }                                                                                    \
+    } while (0)
+
+extern "C" void leann_set_error(const char *fmt, ...);

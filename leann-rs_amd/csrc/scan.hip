@@ -1,0 +1,287 @@
+// scan.hip — exact inner-product scan + top-k selection + cross-shard merge.
+//
+// Replaces the arithmetic of RecomputeSearcher::search once the embeddings exist
+// (src/index/recompute.rs:96-109: N dot products, stable sort descending, take k) and provides
+// the exact ground truth for recall@k.  Scores are raw dot products (higher = better, §3.2 of
+// SURVEY.md), ties keep the lower position (Rust sort_by is stable, N4).
+//
+// Kernels:
+//   score_tile_kernel   S[q][i] = sum_j x_i[j]*q[j] as ONE k-ordered fmaf chain per (q, i)
+//                       (oracle: orc_dot_seqfma; |.-orc_dot_seq| <= 1e-5 is tested) — LDS-tiled,
+//                       128 rows x 64 queries per workgroup, 8x4 register tile per thread.
+//   topk_scores_kernel  per (query, segment of SEG scores): bitonic sort of u64 keys
+//                       (~orderable(score) << 32 | position) in LDS, emit the k smallest.
+//   topk_keys_kernel    same on lists of keys (reduction rounds).
+//   merge_topk_kernel   G-way merge of per-shard lists by (dist, key) — SURVEY.md §8e.
+#include "common.cuh"
+#include "../../include/leann_backend.h"
+#include <algorithm>
+
+#define SEG 2048
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) score_tile_kernel(const float *__restrict__ X, uint64_t n, uint32_t d,
+                                                         uint32_t ld, const float *__restrict__ Q, uint32_t nq,
+                                                         uint32_t ldq, uint64_t row0, uint32_t n_rows,
+                                                         float *__restrict__ S /* [nq x n_rows] */) {
+    constexpr int BR = 128, BQ = 64, BK = 16;
+    __shared__ float sA[BK][BR + 4];
+    __shared__ float sB[BK][BQ + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4; // ty: 16 row groups of 8, tx: 16 query groups of 4
+    const uint32_t rbase = blockIdx.x * BR, qbase = blockIdx.y * BQ;
+    float acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
+    for (uint32_t k0 = 0; k0 < d; k0 += BK) {
+        // stage A: 128 rows x 16 k  (each thread 8 floats), B: 64 queries x 16 k (4 floats)
+        {
+            int r = tid >> 1, kk = (tid & 1) * 8;
+            uint32_t row = rbase + r;
+            const float *src = X + (size_t)(row0 + row) * ld + k0 + kk;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                sA[kk + e][r] = (row < n_rows && k0 + kk + e < d) ? src[e] : 0.f;
+            int qq = tid >> 2, kq = (tid & 3) * 4;
+            uint32_t qi = qbase + qq;
+            const float *qs = Q + (size_t)qi * ldq + k0 + kq;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                sB[kq + e][qq] = (qi < nq && k0 + kq + e < d) ? qs[e] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk++) {
+            float a[8], b[4];
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = sA[kk][ty * 8 + i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = sB[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t qi = qbase + tx * 4 + j;
+        if (qi >= nq) continue;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t row = rbase + ty * 8 + i;
+            if (row < n_rows) S[(size_t)qi * n_rows + row] = acc[i][j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-wide bitonic sort of SEG u64 keys in LDS (ascending), 256 threads.
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *k, int n /* power of two */) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
+                int lo = 2 * i - (i & (stride - 1));
+                int hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                uint64_t a = k[lo], b = k[hi];
+                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// scores S[q][n_rows] -> cand[q][seg][k]; key = ~orderable(score) << 32 | (row0 + row)   (position < 2^32)
+__global__ void __launch_bounds__(256) topk_scores_kernel(const float *__restrict__ S, uint32_t n_rows, uint64_t row0,
+                                                          const uint8_t *__restrict__ allow, uint32_t k,
+                                                          uint64_t *__restrict__ cand, uint32_t cand_stride_q,
+                                                          uint32_t seg_off) {
+    __shared__ uint64_t keys[SEG];
+    const uint32_t seg = blockIdx.x, q = blockIdx.y;
+    const float *s = S + (size_t)q * n_rows;
+    for (int i = threadIdx.x; i < SEG; i += blockDim.x) {
+        uint32_t row = seg * SEG + i;
+        uint64_t key = ~0ull;
+        if (row < n_rows) {
+            uint64_t pos = row0 + row;
+            bool ok = allow ? ((allow[pos >> 3] >> (pos & 7)) & 1) : true;
+            if (ok) key = ((uint64_t)(~f32_orderable(s[row])) << 32) | (uint32_t)pos;
+        }
+        keys[i] = key;
+    }
+    bitonic_sort_lds(keys, SEG);
+    uint64_t *out = cand + (size_t)q * cand_stride_q + (size_t)(seg_off + seg) * k;
+    for (int i = threadIdx.x; i < (int)k; i += blockDim.x) out[i] = keys[i];
+}
+
+// lists in[q][m] -> out[q][nseg][k]
+__global__ void __launch_bounds__(256) topk_keys_kernel(const uint64_t *__restrict__ in, uint32_t m, uint32_t in_stride_q,
+                                                        uint32_t k, uint64_t *__restrict__ out, uint32_t out_stride_q) {
+    __shared__ uint64_t keys[SEG];
+    const uint32_t seg = blockIdx.x, q = blockIdx.y;
+    const uint64_t *src = in + (size_t)q * in_stride_q;
+    for (int i = threadIdx.x; i < SEG; i += blockDim.x) {
+        uint32_t p = seg * SEG + i;
+        keys[i] = p < m ? src[p] : ~0ull;
+    }
+    bitonic_sort_lds(keys, SEG);
+    uint64_t *dst = out + (size_t)q * out_stride_q + (size_t)seg * k;
+    for (int i = threadIdx.x; i < (int)k; i += blockDim.x) dst[i] = keys[i];
+}
+
+__global__ void finalize_scan_kernel(const uint64_t *__restrict__ keys, uint32_t stride_q, uint32_t nq, uint32_t k,
+                                     uint64_t key_offset, uint64_t *__restrict__ out_keys, float *__restrict__ out_scores,
+                                     uint32_t *__restrict__ out_counts) {
+    uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        uint64_t key = keys[(size_t)q * stride_q + i];
+        size_t o = (size_t)q * k + i;
+        if (key != ~0ull) {
+            out_keys[o] = (key & 0xFFFFFFFFull) + key_offset;
+            out_scores[o] = orderable_f32(~(uint32_t)(key >> 32));
+        } else {
+            out_keys[o] = ~0ull;
+            out_scores[o] = __uint_as_float(0xFF800000u); // -inf
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t i = 0; i < k; i++) cnt += keys[(size_t)q * stride_q + i] != ~0ull;
+        out_counts[q] = cnt;
+    }
+}
+
+extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims, size_t ld, const float *d_queries,
+                                      size_t nq, size_t top_k, const uint8_t *d_allow_mask, uint64_t key_offset,
+                                      uint64_t *d_keys, float *d_scores, uint32_t *d_counts, void *stream) {
+    if (!d_queries || !d_keys || !d_scores || !d_counts || dims == 0 || ld < dims || top_k == 0 || top_k > SEG / 2 ||
+        n >= (1ull << 32)) {
+        leann_set_error("leann_scan_topk_device: invalid arguments (n=%zu dims=%zu top_k=%zu)", n, dims, top_k);
+        return LEANN_ERR_INVALID;
+    }
+    if (nq == 0) return LEANN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t k = (uint32_t)top_k;
+    // chunk rows so that the score slab stays <= ~2 GiB
+    size_t chunk = std::max<size_t>(SEG, std::min<size_t>(n ? n : 1, ((size_t)1 << 29) / std::max<size_t>(nq, 1)));
+    chunk = (chunk + SEG - 1) / SEG * SEG;
+    size_t n_chunks = n ? (n + chunk - 1) / chunk : 0;
+    size_t total_segs = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        size_t rows = std::min(chunk, n - c * chunk);
+        total_segs += (rows + SEG - 1) / SEG;
+    }
+    if (total_segs == 0) total_segs = 1;
+    float *S = nullptr;
+    uint64_t *candA = nullptr, *candB = nullptr;
+    size_t cand_len = std::max<size_t>(total_segs * k, k); // per query
+    HIP_CHECK_RET(hipMallocAsync((void **)&S, sizeof(float) * nq * std::max<size_t>(chunk, 1), st));
+    HIP_CHECK_RET(hipMallocAsync((void **)&candA, sizeof(uint64_t) * nq * cand_len, st));
+    HIP_CHECK_RET(hipMallocAsync((void **)&candB, sizeof(uint64_t) * nq * cand_len, st));
+    HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
+    size_t seg_off = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        size_t row0 = c * chunk, rows = std::min(chunk, n - row0);
+        dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
+        hipLaunchKernelGGL(score_tile_kernel, g1, dim3(256), 0, st, d_rows, (uint64_t)n, (uint32_t)dims, (uint32_t)ld,
+                           d_queries, (uint32_t)nq, (uint32_t)dims, (uint64_t)row0, (uint32_t)rows, S);
+        unsigned segs = (unsigned)((rows + SEG - 1) / SEG);
+        hipLaunchKernelGGL(topk_scores_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, S, (uint32_t)rows,
+                           (uint64_t)row0, d_allow_mask, k, candA, (uint32_t)cand_len, (uint32_t)seg_off);
+        seg_off += segs;
+    }
+    HIP_CHECK_RET(hipGetLastError());
+    // reduction rounds until one segment per query remains
+    size_t m = total_segs * k;
+    uint64_t *src = candA, *dst = candB;
+    while (m > k) {
+        unsigned segs = (unsigned)((m + SEG - 1) / SEG);
+        hipLaunchKernelGGL(topk_keys_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, src, (uint32_t)m,
+                           (uint32_t)cand_len, k, dst, (uint32_t)cand_len);
+        m = (size_t)segs * k;
+        std::swap(src, dst);
+        if (segs == 1) break;
+    }
+    hipLaunchKernelGGL(finalize_scan_kernel, dim3((unsigned)nq), dim3(64), 0, st, src, (uint32_t)cand_len, (uint32_t)nq,
+                       k, key_offset, d_keys, d_scores, d_counts);
+    HIP_CHECK_RET(hipGetLastError());
+    HIP_CHECK_RET(hipFreeAsync(S, st));
+    HIP_CHECK_RET(hipFreeAsync(candA, st));
+    HIP_CHECK_RET(hipFreeAsync(candB, st));
+    return LEANN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross-shard merge.  One wave per query; n_shards*k_in <= 4096 entries.
+// Order: ascending (orderable(dist), key)  [descending != 0: descending score, ascending key].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) merge_topk_kernel(const uint64_t *__restrict__ keys, const float *__restrict__ dists,
+                                                        const uint32_t *__restrict__ counts, uint32_t n_shards,
+                                                        uint32_t nq, uint32_t k_in, uint32_t k_out, int descending,
+                                                        uint64_t *__restrict__ out_keys, float *__restrict__ out_dists,
+                                                        uint32_t *__restrict__ out_counts) {
+    // rank-by-counting: total order has no duplicates across shards (keys are global positions)
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    uint32_t *sd = reinterpret_cast<uint32_t *>(sm);               // [n_shards*k_in] orderable dist
+    uint64_t *sk = reinterpret_cast<uint64_t *>(sm + (((size_t)n_shards * k_in * 4 + 7) & ~(size_t)7));
+    const uint32_t q = blockIdx.x, total = n_shards * k_in;
+    for (uint32_t i = threadIdx.x; i < total; i += 64) {
+        uint32_t s = i / k_in, j = i % k_in;
+        size_t src = ((size_t)s * nq + q) * k_in + j;
+        bool valid = j < counts[(size_t)s * nq + q];
+        uint32_t od = f32_orderable(dists[src]);
+        sd[i] = valid ? (descending ? ~od : od) : 0xFFFFFFFFu;
+        sk[i] = valid ? keys[src] : ~0ull;
+    }
+    __syncthreads();
+    uint32_t nvalid = 0;
+    for (uint32_t s = 0; s < n_shards; s++) nvalid += min(counts[(size_t)s * nq + q], k_in);
+    for (uint32_t i = threadIdx.x; i < total; i += 64) {
+        uint32_t di = sd[i];
+        uint64_t ki = sk[i];
+        if (ki == ~0ull && di == 0xFFFFFFFFu) continue;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < total; j++) {
+            uint32_t dj = sd[j];
+            uint64_t kj = sk[j];
+            rank += (dj < di) || (dj == di && kj < ki);
+        }
+        if (rank < k_out) {
+            out_keys[(size_t)q * k_out + rank] = ki;
+            uint32_t od = descending ? ~di : di;
+            out_dists[(size_t)q * k_out + rank] = orderable_f32(od);
+        }
+    }
+    uint32_t nout = min(nvalid, k_out);
+    for (uint32_t i = threadIdx.x; i < k_out; i += 64) {
+        if (i >= nout) {
+            out_keys[(size_t)q * k_out + i] = ~0ull;
+            out_dists[(size_t)q * k_out + i] = __uint_as_float(descending ? 0xFF800000u : 0x7F800000u);
+        }
+    }
+    if (threadIdx.x == 0) out_counts[q] = nout;
+}
+
+extern "C" int leann_merge_topk_device(const uint64_t *d_keys, const float *d_dists, const uint32_t *d_counts,
+                                       size_t n_shards, size_t nq, size_t k_in, size_t k_out, int descending,
+                                       uint64_t *d_out_keys, float *d_out_dists, uint32_t *d_out_counts, void *stream) {
+    if (!d_keys || !d_dists || !d_counts || !d_out_keys || !d_out_dists || !d_out_counts || n_shards == 0 ||
+        k_in == 0 || k_out == 0 || n_shards * k_in > 4096) {
+        leann_set_error("leann_merge_topk_device: invalid arguments (shards=%zu k_in=%zu k_out=%zu)", n_shards, k_in, k_out);
+        return LEANN_ERR_INVALID;
+    }
+    if (nq == 0) return LEANN_OK;
+    size_t total = n_shards * k_in;
+    size_t lds = ((total * 4 + 7) & ~(size_t)7) + total * 8;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), lds, (hipStream_t)stream, d_keys, d_dists,
+                       d_counts, (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k_in, (uint32_t)k_out, descending,
+                       d_out_keys, d_out_dists, d_out_counts);
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
+}

@@ -1,0 +1,315 @@
+// search.cuh — on-GPU graph traversal for HNSW (level descent + ef beam) and Vamana (single level,
+// medoid entry).  Replaces the arithmetic behind
+//     HnswSearcher::search     src/backend/hnsw.rs:79-88   (usearch::Index::search, out of tree)
+//     DiskAnnSearcher::search  src/backend/diskann.rs:47-62 (diskann_rs search_with_dists, out of tree)
+// Restated algorithm: oracle/oracle.c (search_layer_heap / search_layer_list / graph_search_ctx).
+//
+// Mapping: one workgroup (NW waves of 64) per query.
+//   * query vector: registers of every wave (lane l holds elements 256t+4l..+3), loaded once;
+//   * result/candidate beam W: sorted u64 keys in LDS, double buffered, merged by rank;
+//   * visited set: open-addressing hash table in LDS (global memory in the overflow re-run);
+//   * per hop: wave 0 reads the adjacency list (one neighbour id per lane) and filters it through
+//     the visited table; the not-yet-seen rows are dealt round-robin to the NW waves, each wave
+//     streams a whole row per instruction group (64 lanes x 16 B = 1 KiB coalesced), R rows in
+//     flight, and reduces with the canonical wave tree (common.cuh);
+//   * exactly one candidate is expanded per step, in the same order as the sequential algorithm,
+//     so ids AND distances are bit-identical to the oracle.
+#pragma once
+#include "common.cuh"
+
+struct GraphView {
+    const float *X;            // [n x ld] rows, 16-byte aligned, zero padded
+    const uint32_t *adj0;      // [n x M0] level-0 neighbours, LEANN_EMPTY padded
+    const uint32_t *adjU;      // [n_upper_lists x M] upper-level neighbour lists
+    const uint32_t *upper_off; // [n] first upper list of a node (list of level l at upper_off+l-1)
+    uint64_t n;
+    uint32_t d, ld, M, M0, max_level, entry;
+};
+
+struct SearchArgs {
+    const float *queries;     // [nq x ldq] (ignored when q_rows != nullptr)
+    const uint32_t *q_rows;   // optional: query i is base row q_rows[i] (index construction)
+    const uint32_t *q_map;    // optional: indirection list of query indices (overflow re-run)
+    const uint32_t *q_map_count;
+    uint32_t ldq, nq, k, ef, target_level;
+    uint32_t hash_bits;       // visited table = 1 << hash_bits slots
+    uint64_t key_offset;
+    uint64_t *out_keys;       // [nq x k]
+    float *out_dists;         // [nq x k]
+    uint32_t *out_counts;     // [nq]
+    uint32_t *out_stats;      // [nq x 4] evals, hops0, hopsU, overflowed  (optional)
+    uint32_t *overflow_list;  // LDS-table pass: queries whose table filled up
+    uint32_t *overflow_count;
+    uint32_t *gtables;        // global-table pass: [gridDim.x x (1 << hash_bits)]
+    uint32_t *work_counter;   // global-table pass: persistent work queue head
+};
+
+__device__ __forceinline__ uint32_t vis_hash(uint32_t id, uint32_t bits) {
+    return (id * 0x9E3779B1u) >> (32 - bits);
+}
+
+// ---- distance of up to R rows per wave, all loads issued before the first use -----------------
+template <int T, int R>
+__device__ __forceinline__ void wave_dist_rows(const float4 (&q)[T], const float *__restrict__ X, uint32_t ld,
+                                               const uint32_t (&ids)[R], int nrows, int lane, float (&out)[R]) {
+    float4 v[R][T];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (r < nrows) {
+            const float *row = X + (size_t)ids[r] * ld;
+#pragma unroll
+            for (int t = 0; t < T; t++) v[r][t] = row_load4(row, ld, t, lane);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (r < nrows) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < T; t++) fma4(acc, q[t], v[r][t]);
+            out[r] = 1.0f - wave_tree_sum(lane4_sum(acc));
+        }
+    }
+}
+
+// LDS carve-up (dynamic): [W0 | W1 | s_key | s_new | misc | table]
+struct SearchLds {
+    uint64_t *s_key;
+    uint32_t *s_new;
+    uint32_t *misc;  // [0]=n_new [1],[2]=next selection (double buffered) [3]=abort
+    uint32_t *table; // LDS table (nullptr for the global variant)
+};
+__host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits, bool gtable) {
+    size_t efp = (ef + 1) & ~1u;
+    size_t b = 2 * efp * 8 + (size_t)maxdeg * 8 + (size_t)maxdeg * 4 + 16 * 4;
+    b = (b + 15) & ~(size_t)15;
+    if (!gtable) b += ((size_t)1 << hash_bits) * 4;
+    return b;
+}
+
+template <int T, int R, int NW, bool GTABLE>
+__device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_t qi, unsigned char *smem,
+                                uint32_t *gtable) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ef = a.ef;
+    const uint32_t maxdeg = g.M0 > g.M ? g.M0 : g.M;
+    const uint32_t efp = (ef + 1) & ~1u;
+    SearchLds s;
+    uint64_t *const W0 = reinterpret_cast<uint64_t *>(smem); // buffer b lives at W0 + b*efp (no pointer array: stays out of scratch)
+    s.s_key = W0 + 2 * efp;
+    s.s_new = reinterpret_cast<uint32_t *>(s.s_key + maxdeg);
+    s.misc = s.s_new + maxdeg;
+    size_t off = 2 * (size_t)efp * 8 + (size_t)maxdeg * 12 + 64;
+    off = (off + 15) & ~(size_t)15;
+    uint32_t *table = GTABLE ? gtable : reinterpret_cast<uint32_t *>(smem + off);
+    const uint32_t hbits = a.hash_bits, hsize = 1u << hbits, hmask = hsize - 1;
+    const uint32_t vis_limit = hsize - (hsize >> 2); // 75 % load
+
+    // ---- query into registers -----------------------------------------------------------------
+    float4 q[T];
+    {
+        const float *qv;
+        uint32_t dq = g.d;
+        if (a.q_rows) qv = g.X + (size_t)a.q_rows[qi] * g.ld;
+        else qv = a.queries + (size_t)qi * a.ldq;
+#pragma unroll
+        for (int t = 0; t < T; t++) q[t] = vec_load4_guard(qv, dq, t, lane);
+    }
+
+    uint32_t n_evals = 1, hops0 = 0, hopsU = 0; // meaningful in wave 0 / lane 0 only
+    uint32_t n_vis = 0;
+    uint64_t best;
+    {
+        uint32_t ids[1] = {g.entry};
+        float dd[1];
+        wave_dist_rows<T, 1>(q, g.X, g.ld, ids, 1, lane, dd);
+        best = make_key(dd[0], g.entry); // every wave computes the same value
+    }
+
+    uint32_t wsize = 0;
+    int cur = 0;
+    bool aborted = false;
+    for (int lv = (int)g.max_level; lv >= (int)a.target_level; --lv) {
+        const uint32_t ef_l = (lv == (int)a.target_level) ? ef : 1u;
+        const uint32_t deg = lv == 0 ? g.M0 : g.M;
+        for (uint32_t i = tid; i < hsize; i += NW * 64) table[i] = LEANN_EMPTY;
+        __syncthreads();
+        if (tid == 0) {
+            W0[0] = best;
+            table[vis_hash(key_id(best), hbits)] = key_id(best);
+            s.misc[1] = LEANN_EMPTY;
+            s.misc[2] = LEANN_EMPTY;
+            s.misc[3] = 0;
+        }
+        __syncthreads();
+        cur = 0;
+        wsize = 1;
+        n_vis = 1;
+        uint32_t sel = 0;
+        uint32_t hop = 0;
+        while (sel != LEANN_EMPTY) {
+            uint64_t *Wc = W0 + cur * efp, *Wn = W0 + (cur ^ 1) * efp;
+            // ---- phase B: adjacency list through the visited table (wave 0) ------------------
+            if (wave == 0) {
+                const uint32_t node = key_id(Wc[sel]);
+                const uint32_t *adj = lv == 0 ? g.adj0 + (size_t)node * g.M0
+                                              : g.adjU + ((size_t)g.upper_off[node] + (uint32_t)(lv - 1)) * g.M;
+                uint32_t n_new = 0;
+                bool ovf = (n_vis + deg > vis_limit);
+                if (!ovf) {
+                    for (uint32_t base = 0; base < deg; base += 64) {
+                        uint32_t e = (base + lane < deg) ? adj[base + lane] : LEANN_EMPTY;
+                        bool isnew = false;
+                        if (e != LEANN_EMPTY) {
+                            uint32_t h = vis_hash(e, hbits);
+                            for (;;) {
+                                uint32_t old = atomicCAS(&table[h], LEANN_EMPTY, e);
+                                if (old == LEANN_EMPTY) { isnew = true; break; }
+                                if (old == e) break;
+                                h = (h + 1) & hmask;
+                            }
+                        }
+                        unsigned long long m = __ballot(isnew);
+                        uint32_t pos = n_new + __popcll(m & ((1ull << lane) - 1ull));
+                        if (isnew) s.s_new[pos] = e;
+                        n_new += __popcll(m);
+                    }
+                }
+                n_vis += n_new;
+                n_evals += n_new;
+                if (lv == 0) hops0++; else hopsU++;
+                if (lane == 0) {
+                    s.misc[0] = n_new;
+                    s.misc[1 + (hop & 1)] = LEANN_EMPTY; // slot THIS hop's merge mins into (last read two hops ago)
+                    if (ovf) s.misc[3] = 1;
+                }
+            }
+            __syncthreads(); // B1
+            if (s.misc[3]) { aborted = true; break; }
+            const uint32_t n_new = s.misc[0];
+            // ---- phase C: stream the new rows, R in flight per wave ------------------------------
+            for (uint32_t j0 = wave; j0 < n_new; j0 += NW * R) {
+                uint32_t ids[R];
+                float dd[R];
+                int nrows = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    uint32_t j = j0 + r * NW;
+                    if (j < n_new) { ids[r] = s.s_new[j]; nrows = r + 1; }
+                }
+                wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if (r < nrows) s.s_key[j0 + r * NW] = make_key(dd[r], ids[r]);
+                }
+            }
+            __syncthreads(); // B2
+            // ---- phase D: merge by rank into the other buffer; pick the next candidate ----------
+            uint32_t *next_slot = &s.misc[1 + (hop & 1)];
+            for (uint32_t t = tid; t < wsize; t += NW * 64) {
+                uint64_t k = Wc[t];
+                if (t == sel) k |= 1ull;
+                uint32_t cnt = 0;
+                for (uint32_t j = 0; j < n_new; j++) cnt += (s.s_key[j] >> 1) < (k >> 1);
+                uint32_t rank = t + cnt;
+                if (rank < ef_l) {
+                    Wn[rank] = k;
+                    if (!(k & 1ull)) atomicMin(next_slot, rank);
+                }
+            }
+            for (uint32_t j = tid; j < n_new; j += NW * 64) {
+                uint64_t k = s.s_key[j];
+                uint32_t lo = 0, hi = wsize;
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if ((Wc[mid] >> 1) < (k >> 1)) lo = mid + 1; else hi = mid;
+                }
+                uint32_t cnt = lo;
+                for (uint32_t jj = 0; jj < n_new; jj++) cnt += s.s_key[jj] < k;
+                if (cnt < ef_l) {
+                    Wn[cnt] = k;
+                    atomicMin(next_slot, cnt);
+                }
+            }
+            __syncthreads(); // B3
+            sel = *next_slot;
+            wsize = min(wsize + n_new, ef_l);
+            cur ^= 1;
+            hop++;
+        }
+        if (aborted) break;
+        best = W0[cur * efp] & ~1ull;
+        __syncthreads(); // everyone has read `best` before the next level rewrites W[0]
+    }
+
+    // ---- results ------------------------------------------------------------------------------
+    if (aborted) {
+        if (!GTABLE) {
+            if (tid == 0) {
+                uint32_t slot = atomicAdd(a.overflow_count, 1u);
+                a.overflow_list[slot] = qi;
+            }
+        } else { // even the 2^20-slot table filled up: report an empty result, flagged in the stats
+            for (uint32_t t = tid; t < a.k; t += NW * 64) {
+                a.out_keys[(size_t)qi * a.k + t] = 0xFFFFFFFFFFFFFFFFull;
+                a.out_dists[(size_t)qi * a.k + t] = __uint_as_float(0x7F800000u);
+            }
+            if (tid == 0) {
+                a.out_counts[qi] = 0;
+                if (a.out_stats) a.out_stats[(size_t)qi * 4 + 3] = 2u;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    const uint32_t nout = min(wsize, a.k);
+    uint64_t *Wc = W0 + cur * efp;
+    for (uint32_t t = tid; t < a.k; t += NW * 64) {
+        size_t o = (size_t)qi * a.k + t;
+        if (t < nout) {
+            uint64_t k = Wc[t];
+            a.out_keys[o] = (uint64_t)key_id(k) + a.key_offset;
+            a.out_dists[o] = key_dist(k);
+        } else {
+            a.out_keys[o] = 0xFFFFFFFFFFFFFFFFull;
+            a.out_dists[o] = __uint_as_float(0x7F800000u);
+        }
+    }
+    if (tid == 0) {
+        a.out_counts[qi] = nout;
+        if (a.out_stats) {
+            a.out_stats[(size_t)qi * 4 + 0] = n_evals;
+            a.out_stats[(size_t)qi * 4 + 1] = hops0;
+            a.out_stats[(size_t)qi * 4 + 2] = hopsU;
+            a.out_stats[(size_t)qi * 4 + 3] = GTABLE ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+}
+
+// One workgroup per query; visited table in LDS.
+template <int T, int R, int NW>
+__global__ void __launch_bounds__(NW * 64) beam_search_lds_kernel(GraphView g, SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    beam_search_one<T, R, NW, false>(g, a, qi, smem, nullptr);
+}
+
+// Overflow re-run: a few persistent workgroups drain the overflow list with a big table in HBM.
+template <int T, int R, int NW>
+__global__ void __launch_bounds__(NW * 64) beam_search_gtable_kernel(GraphView g, SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_item;
+    const uint32_t total = *a.q_map_count;
+    uint32_t *gt = a.gtables + ((size_t)blockIdx.x << a.hash_bits);
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(a.work_counter, 1u);
+        __syncthreads();
+        uint32_t item = s_item;
+        __syncthreads();
+        if (item >= total) break; // uniform exit: every wave leaves on the same item
+        beam_search_one<T, R, NW, true>(g, a, a.q_map[item], smem, gt);
+    }
+}

@@ -1,0 +1,109 @@
+/*
+ * oracle.h — CPU restatement of the leann-rs ANN search hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product path (leann-rs_amd/csrc) never links, loads or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" for HNSW / DiskANN search.  The reference delegates that
+ * arithmetic to the un-vendored crates usearch 2.23.0 (Cargo.lock:4381-4388), diskann-rs 0.3.4
+ * (Cargo.lock:987-1001) and anndists 0.1.3 (Cargo.lock:59-72); no reference test pins a search
+ * result.  What is restated here is the published algorithm (HNSW: Malkov &
+ * Yashunin arXiv:1603.09320 Alg. 1/2/4/5; Vamana: Subramanya et al. NeurIPS'19 Alg. 1/2/3)
+ * anchored on the reference call sites:
+ *     src/backend/hnsw.rs:43-51,79-88,112-130   (IP metric, f32, key = insertion position)
+ *     src/backend/diskann.rs:47-62,88-92        (beam = max(complexity, k), alpha = 1.2, DistDot)
+ * The in-tree arithmetic IS restated literally and pinned by tests/golden:
+ *     src/index/recompute.rs:96-109,137-139     (sequential dot, stable sort desc, take k)
+ *     src/index/bm25.rs:135-170                 (hybrid_rerank)
+ *
+ * Distance convention: dist = 1 - <q, x>, lower is better, results ascending
+ * by (dist, key).  Every comparison is on the total order given by the 64-bit packed key
+ *     key64 = orderable(dist) << 32 | id
+ * so ties in distance resolve to the lower id on CPU and GPU alike.
+ *
+ * Canonical dot product ("wave order", shared by the HIP traversal kernel):
+ *     256 strided accumulators a[i], i = 0..255; element j of the vectors goes to a[j mod 256]
+ *     by an fmaf chain in increasing j; the 256 accumulators are then summed by a perfect
+ *     adjacent-pair tree (a0+a1),(a2+a3),... (8 levels).  This is exactly what a 64-lane
+ *     wavefront computes with float4 loads (lane l owns a[4l..4l+3]) followed by an xor
+ *     butterfly over lane masks 1,2,4,8,16,32.
+ */
+#ifndef LEANN_ORACLE_H
+#define LEANN_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_EMPTY 0xFFFFFFFFu
+
+/* ---- deterministic synthetic data ---------------------------------------- */
+uint64_t orc_mix64(uint64_t x);
+uint64_t orc_hash3(uint64_t seed, uint64_t a, uint64_t b);
+float orc_gauss(uint64_t seed, uint64_t a, uint64_t b);
+/* rows i0..i0+n of stream `stream` (0 = corpus, 1 = queries); r == 0 -> i.i.d. mode */
+void orc_gen_rows(uint64_t seed, uint32_t d, uint32_t r, uint32_t n_clusters, float sigma,
+                  uint32_t stream, uint64_t i0, uint64_t n, float *out);
+
+/* ---- dot products -------------------------------------------------------------------------- */
+float orc_dot_canon(const float *a, const float *b, uint32_t d);     /* wave order (see above) */
+float orc_dot_canon_ref(const float *a, const float *b, uint32_t d); /* same, scalar definition */
+float orc_dot_seq(const float *a, const float *b, uint32_t d);       /* recompute.rs:137-139 literal */
+float orc_dot_seqfma(const float *a, const float *b, uint32_t d);    /* k-ordered fmaf chain (MFMA f32 order) */
+
+uint32_t orc_f32_orderable(float f);
+float orc_orderable_f32(uint32_t u);
+
+/* ---- recompute / brute-force scan (src/index/recompute.rs:96-109) ------------------------- */
+/* mode 0: orc_dot_seq (literal), 1: orc_dot_seqfma, 2: orc_dot_canon.  Scores descending,
+ * stable (ties keep ascending position), NaN compares Equal like partial_cmp().unwrap_or(Equal). */
+void orc_scan_topk(const float *X, uint64_t n, uint32_t d, const float *q, uint32_t k, int mode,
+                   const uint8_t *allow_mask, uint64_t *keys, float *scores, uint32_t *n_out);
+
+/* ---- graph index -------------------------------------------------------------------------- */
+typedef struct orc_graph orc_graph;
+
+uint32_t orc_level(uint64_t seed, uint64_t i, uint32_t M);
+
+/* sequential insertion in position order (hnsw.rs:128-130) */
+orc_graph *orc_hnsw_build(const float *X, uint64_t n, uint32_t d, uint32_t M, uint32_t efc,
+                          uint64_t level_seed);
+/* Vamana: random R-regular start, two passes (alpha 1.0 then `alpha`), medoid entry */
+orc_graph *orc_vamana_build(const float *X, uint64_t n, uint32_t d, uint32_t R, uint32_t L,
+                            float alpha, uint64_t seed);
+/* borrow flat arrays (e.g. a graph built on the GPU) — arrays must outlive the handle */
+orc_graph *orc_graph_from_arrays(const float *X, uint64_t n, uint32_t d, uint32_t ld, uint32_t M,
+                                 uint32_t M0, uint32_t max_level, uint32_t entry,
+                                 const uint8_t *levels, const uint32_t *upper_off,
+                                 const uint32_t *adj0, const uint32_t *adjU, uint64_t n_upper_lists);
+void orc_graph_info(const orc_graph *g, uint64_t *out /* n,d,ld,M,M0,max_level,entry,n_upper_lists */);
+void orc_graph_export(const orc_graph *g, uint8_t *levels, uint32_t *upper_off, uint32_t *adj0,
+                      uint32_t *adjU);
+void orc_graph_free(orc_graph *g);
+
+/* stats[0]=distance evaluations, [1]=level-0 expansions, [2]=upper-level expansions */
+/* algo 0: two-heap HNSW SEARCH-LAYER (Malkov Alg. 2);  algo 1: sorted-list GreedySearch (Vamana Alg. 1) */
+int orc_graph_search(const orc_graph *g, const float *q, uint32_t k, uint32_t ef, int algo,
+                     uint64_t *keys, float *dists, uint32_t *n_out, uint64_t *stats);
+int orc_graph_search_batch(const orc_graph *g, const float *Q, uint64_t nq, uint32_t k, uint32_t ef,
+                           int algo, uint32_t nthreads, uint64_t *keys, float *dists,
+                           uint32_t *counts, uint64_t *stats /* [nq*3] or NULL */);
+
+/* ---- top-k merge of per-shard results (new) --------------------------------- */
+void orc_merge_topk(const uint64_t *keys, const float *dists, const uint32_t *counts,
+                    uint32_t n_shards, uint32_t k_in, uint32_t k_out, uint64_t *out_keys,
+                    float *out_dists, uint32_t *out_n);
+
+/* ---- hybrid rerank (src/index/bm25.rs:135-170) --------------------------------------------- */
+void orc_hybrid_rerank(const uint64_t *idx, const float *vscore, uint32_t n, const float *bm25,
+                       uint64_t n_bm25, float alpha, uint64_t *out_idx, float *out_score);
+
+/* ---- pooling / normalise glue (src/embedding/candle.rs:191-225) ---------------------------- */
+void orc_l2_normalize(float *x, uint32_t d); /* x / max(sqrt(sum x^2), 1e-12), sequential sum */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

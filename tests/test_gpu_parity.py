@@ -1,0 +1,232 @@
+"""-m gpu: HIP path vs the CPU oracle on the same seeded inputs, through the C ABI.
+Bar: ids bit-exact, distances bit-exact (the canonical wave-order dot is shared), stats identical."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import SEED, recall_at_k, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_search(la, s, Q, k, ef):
+    keys, dists, counts = s.search_batch(Q, k, ef)
+    return keys, dists, counts
+
+
+def _assert_same(po, G, s, Q, k, ef, algo=0):
+    ok, od, oc, ost = G.search_batch(Q, k, ef, algo, nthreads=8)
+    s.stats(reset=True)
+    gk, gd, gc = s.search_batch(Q, k, ef)
+    st = s.stats()
+    assert (gc == oc).all()
+    assert (gk == ok).all(), f"ids differ in {(gk != ok).any(axis=1).sum()} of {len(Q)} queries"
+    assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+    assert st["n_dist_evals"] == int(ost[:, 0].sum())
+    assert st["n_hops_base"] == int(ost[:, 1].sum())
+    assert st["n_hops_upper"] == int(ost[:, 2].sum())
+    return gk
+
+
+@pytest.mark.parametrize("d,r", [(128, 0), (128, 32), (768, 64), (1536, 64), (100, 16), (260, 8)])
+def test_synth_rows_bit_exact(la, po, gpu, d, r):
+    n = 300
+    ld = (d + 3) // 4 * 4
+    for stream, i0 in ((0, 0), (1, 12345)):
+        ref = po.gen_rows(SEED, d, r, 97, 0.7, stream, i0, n)
+        buf = la.DeviceArray((n, ld), np.float32)
+        la._native.check(la.lib().leann_synth_rows_device(SEED, d, ld, r, 97, 0.7, stream, i0, n, buf.ptr, None))
+        la.sync()
+        got = buf.to_host()
+        assert (got[:, :d].view(np.uint32) == ref.view(np.uint32)).all()
+        assert (got[:, d:] == 0).all()
+
+
+@pytest.mark.parametrize("n,d,M,ef", [(3000, 128, 16, 64), (2000, 768, 32, 128), (1500, 1536, 8, 32), (800, 100, 4, 10)])
+def test_hnsw_search_matches_oracle(la, po, gpu, n, d, M, ef):
+    X = synth(po, n, d)
+    Q = synth(po, 64, d, stream=1)
+    G = po.Graph.build_hnsw(X, M=M, efc=64)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, M, 2 * M, G.max_level, G.entry, lv, uo, a0, aU)
+    assert s.len() == n and not s.is_empty()
+    for k, e in ((10, ef), (1, 1), (5, 3), (ef, ef)):
+        _assert_same(po, G, s, Q, k, e)
+    # single-query trait call == batch row
+    k1, d1 = s.search(Q[3], 10, ef)
+    ok, od, _ = G.search(Q[3], 10, ef)
+    assert (k1 == ok).all() and (d1 == od).all()
+    s.close()
+
+
+def test_vamana_search_matches_oracle(la, po, gpu):
+    n, d, R = 2500, 128, 24
+    X = synth(po, n, d)
+    Q = synth(po, 50, d, stream=1)
+    G = po.Graph.build_vamana(X, R=R, L=48, alpha=1.2)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.DiskAnn, X, R, R, 0, G.entry, lv, uo, a0, aU)
+    for k, L in ((10, 64), (10, 5), (3, 128)):
+        _assert_same(po, G, s, Q, k, L, algo=1)
+    s.close()
+
+
+def test_duplicates_and_ties(la, po, gpu):
+    """Adversarial: every vector appears 4 times -> exact distance ties must resolve to the lower id."""
+    base = synth(po, 500, 128)
+    X = np.concatenate([base, base, base, base])
+    Q = np.concatenate([base[:20], synth(po, 20, 128, stream=1)])
+    G = po.Graph.build_hnsw(X, M=8, efc=32)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, 8, 16, G.max_level, G.entry, lv, uo, a0, aU)
+    _assert_same(po, G, s, Q, 8, 40)
+    s.close()
+
+
+def test_tiny_and_short_results(la, po, gpu):
+    X = synth(po, 5, 128)
+    Q = synth(po, 3, 128, stream=1)
+    G = po.Graph.build_hnsw(X, M=4, efc=8)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, 4, 8, G.max_level, G.entry, lv, uo, a0, aU)
+    gk, gd, gc = s.search_batch(Q, 10, 64)  # top_k > n: short result, padded
+    assert (gc == 5).all()
+    assert (gk[:, 5:] == np.iinfo(np.uint64).max).all() and np.isinf(gd[:, 5:]).all()
+    _assert_same(po, G, s, Q, 10, 64)
+    s.close()
+
+
+def test_visited_table_overflow_rerun(la, po, gpu):
+    """ef=16 gives a 1024-slot LDS table; a dense graph overflows it and the query is re-run with the
+    HBM table — results must not change."""
+    n, d, M = 6000, 128, 32
+    X = synth(po, n, d, r=0)  # i.i.d.: searches wander
+    Q = synth(po, 32, d, stream=1, r=0)
+    G = po.Graph.build_hnsw(X, M=M, efc=32)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, M, 2 * M, G.max_level, G.entry, lv, uo, a0, aU)
+    _assert_same(po, G, s, Q, 10, 16)
+    assert s.stats()["n_table_overflow"] > 0
+    s.close()
+
+
+def test_gpu_built_hnsw(la, po, gpu, tmp_path):
+    n, d, M = 20000, 128, 16
+    X = synth(po, n, d)
+    Q = synth(po, 200, d, stream=1)
+    stem = str(tmp_path / "documents.leann")
+    la.BackendBuilder(la.BackendType.Hnsw).build(X, [], stem, d, M, 64)
+    s = la.HnswSearcher.load(stem, d)
+    g = s.graph_export(with_vectors=True)
+    assert g["n"] == n and g["M"] == M and g["M0"] == 2 * M
+    assert (g["vectors"] == X).all()
+    a0 = g["adj0"]
+    valid = a0 != 0xFFFFFFFF
+    assert (a0[valid] < n).all()
+    deg = valid.sum(1)
+    assert deg.min() >= 1 and deg.max() <= 2 * M
+    assert (valid[:, :-1] >= valid[:, 1:]).all()  # lists compact
+    rows = np.repeat(np.arange(n), 2 * M).reshape(n, 2 * M)
+    assert not (a0 == rows).any()  # no self loops
+    srt = np.sort(a0, axis=1)
+    assert not ((srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] != 0xFFFFFFFF)).any()  # no duplicates
+    # levels follow the shared hash
+    assert (g["levels"] == np.array([po.lib().orc_level(0x5EED0003, i, M) for i in range(n)], np.uint8)).all()
+    # the oracle searching the GPU-built graph agrees bit for bit with the GPU searching it
+    G = po.Graph.from_arrays(X, M, 2 * M, g["max_level"], g["entry"], g["levels"], g["upper_off"], a0, g["adjU"])
+    gk = _assert_same(po, G, s, Q, 10, 64)
+    truth = po.exact_topk(X, Q, 10)
+    assert recall_at_k(gk, truth) >= 0.95
+    s.close()
+
+
+def test_gpu_built_vamana(la, po, gpu, tmp_path):
+    n, d, R = 10000, 128, 32
+    X = synth(po, n, d)
+    Q = synth(po, 100, d, stream=1)
+    stem = str(tmp_path / "documents.leann")
+    la.BackendBuilder(la.BackendType.DiskAnn).build(X, [], stem, d, R, 64)
+    s = la.DiskAnnSearcher.load(stem, d)
+    g = s.graph_export()
+    assert g["max_level"] == 0 and g["M0"] == R
+    G = po.Graph.from_arrays(X, R, R, 0, g["entry"], g["levels"], g["upper_off"], g["adj0"], g["adjU"])
+    gk = _assert_same(po, G, s, Q, 10, 64, algo=1)
+    assert recall_at_k(gk, po.exact_topk(X, Q, 10)) >= 0.9
+    with pytest.raises(la.LeannError, match="does not support incremental"):
+        la.BackendBuilder(la.BackendType.DiskAnn).add_to_index(X[:10], stem, d, n)
+    s.close()
+
+
+def test_scan_topk_matches_recompute_restatement(la, po, gpu):
+    n, d, nq, k = 5000, 768, 9, 10
+    X = synth(po, n, d)
+    Q = synth(po, nq, d, stream=1)
+    dX, dQ = la.DeviceArray.from_host(X), la.DeviceArray.from_host(Q)
+    dk, ds, dc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    la._native.check(la.lib().leann_scan_topk_device(dX.ptr, n, d, d, dQ.ptr, nq, k, None, 0, dk.ptr, ds.ptr, dc.ptr, None))
+    la.sync()
+    gk, gs, gc = dk.to_host(), ds.to_host(), dc.to_host()
+    assert (gc == k).all()
+    for i in range(nq):
+        k1, s1 = po.scan_topk(X, Q[i], k, mode=1)  # k-ordered fmaf chain: bit-exact
+        assert (gk[i] == k1).all() and (gs[i].view(np.uint32) == s1.view(np.uint32)).all()
+        k0, s0 = po.scan_topk(X, Q[i], k, mode=0)  # literal recompute.rs:137-139: within 1e-5
+        assert np.abs(gs[i] - s0).max() <= 1e-5
+        assert set(gk[i].tolist()) == set(k0.tolist()) or np.abs(np.sort(s0) - np.sort(gs[i])).max() <= 1e-5
+
+
+def test_scan_topk_allow_mask_and_ties(la, po, gpu):
+    base = synth(po, 300, 128)
+    X = np.concatenate([base, base])  # ties: the lower position must win (stable sort, N4)
+    Q = base[:4].copy()
+    n, d, nq, k = X.shape[0], 128, 4, 6
+    mask = np.zeros((n + 7) // 8, np.uint8)
+    allowed = np.arange(n) % 3 != 0
+    for i in np.nonzero(allowed)[0]:
+        mask[i >> 3] |= 1 << (i & 7)
+    dX, dQ, dM = la.DeviceArray.from_host(X), la.DeviceArray.from_host(Q), la.DeviceArray.from_host(mask)
+    dk, ds, dc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    la._native.check(la.lib().leann_scan_topk_device(dX.ptr, n, d, d, dQ.ptr, nq, k, dM.ptr, 0, dk.ptr, ds.ptr, dc.ptr, None))
+    la.sync()
+    gk, gs = dk.to_host(), ds.to_host()
+    for i in range(nq):
+        k1, s1 = po.scan_topk(X, Q[i], k, mode=1, allow_mask=mask)
+        assert (gk[i] == k1).all() and (gs[i] == s1).all()
+
+
+def test_merge_topk_matches_oracle(la, po, gpu):
+    rng = np.random.default_rng(5)
+    S, nq, k_in, k_out = 8, 33, 10, 10
+    keys = rng.permutation(S * nq * k_in).astype(np.uint64).reshape(S, nq, k_in)
+    dists = rng.integers(0, 40, (S, nq, k_in)).astype(np.float32) / 8  # many ties
+    for s_ in range(S):  # valid inputs: each list ascending by (dist, key)
+        for q in range(nq):
+            o = np.lexsort((keys[s_, q], dists[s_, q]))
+            keys[s_, q], dists[s_, q] = keys[s_, q][o], dists[s_, q][o]
+    counts = rng.integers(0, k_in + 1, (S, nq)).astype(np.uint32)
+    dk, dd, dc = la.DeviceArray.from_host(keys), la.DeviceArray.from_host(dists), la.DeviceArray.from_host(counts)
+    ok, od, oc = la.DeviceArray((nq, k_out), np.uint64), la.DeviceArray((nq, k_out), np.float32), la.DeviceArray(nq, np.uint32)
+    la._native.check(la.lib().leann_merge_topk_device(dk.ptr, dd.ptr, dc.ptr, S, nq, k_in, k_out, 0, ok.ptr, od.ptr, oc.ptr, None))
+    la.sync()
+    gk, gd, gc = ok.to_host(), od.to_host(), oc.to_host()
+    for q in range(nq):
+        rk, rd = po.merge_topk(keys[:, q], dists[:, q], counts[:, q], k_out)
+        m = len(rk)
+        assert int(gc[q]) == m
+        assert (gk[q, :m] == rk).all() and (gd[q, :m] == rd).all()
+        assert (gk[q, m:] == np.iinfo(np.uint64).max).all()
+
+
+def test_open_errors(la, gpu, tmp_path):
+    stem = str(tmp_path / "documents.leann")
+    with pytest.raises(la.LeannError, match="Index file not found"):
+        la.HnswSearcher.load(stem, 128)
+    with pytest.raises(la.LeannError, match="DiskANN index not found"):
+        la.DiskAnnSearcher.load(stem, 128)
+    (tmp_path / "documents.index").write_bytes(b"IxHN" + b"\0" * 64)
+    with pytest.raises(la.LeannError, match="Python LEANN"):
+        la.HnswSearcher.load(stem, 128)
+    (tmp_path / "documents.index").write_bytes(b"garbage!" * 32)
+    with pytest.raises(la.LeannError, match="incompatible format"):
+        la.HnswSearcher.load(stem, 128)

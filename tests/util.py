@@ -1,0 +1,17 @@
+import numpy as np
+
+# synthetic-set defaults: seed, r, clusters, sigma
+SEED = 0x5EED0001
+GEN = dict(r=64, n_clusters=4096, sigma=1.0)
+
+
+def synth(po, n, d, stream=0, i0=0, r=64, n_clusters=256, sigma=1.0, seed=SEED):
+    return po.gen_rows(seed, d, r, n_clusters, sigma, stream, i0, n)
+
+
+def recall_at_k(found, truth):
+    k = truth.shape[1]
+    hits = 0
+    for f, t in zip(found, truth):
+        hits += len(set(int(x) for x in f[:k]) & set(int(x) for x in t))
+    return hits / (len(truth) * k)
