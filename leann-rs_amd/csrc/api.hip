@@ -60,9 +60,6 @@ extern "C" int leann_device_sync(int device) {
 // ---- handle (structs in internal.h) ---------------------------------------------------------------
 static void ws_free(Workspace *w) {
     if (!w) return;
-    (void)hipFree(w->overflow_list);
-    (void)hipFree(w->ctrs);
-    (void)hipFree(w->gtables);
     (void)hipFree(w->d_q);
     (void)hipFree(w->d_keys);
     (void)hipFree(w->d_dists);
@@ -71,17 +68,19 @@ static void ws_free(Workspace *w) {
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }
-static int ws_ensure(Workspace *w, size_t nq) {
-    if (!w->ctrs) {
-        HIP_CHECK_RET(hipMalloc((void **)&w->ctrs, 16));
-        HIP_CHECK_RET(hipMalloc((void **)&w->gtables, ((size_t)GT_BLOCKS << GT_BITS) * 4));
-    }
-    if (nq > w->cap_nq) {
-        (void)hipFree(w->overflow_list);
-        w->overflow_list = nullptr;
-        HIP_CHECK_RET(hipMalloc((void **)&w->overflow_list, nq * 4));
-        w->cap_nq = nq;
-    }
+static int ensure_gpool(leann_backend *h) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->gpool) return LEANN_OK;
+    unsigned long long *p = nullptr;
+    uint32_t *lock = nullptr;
+    const size_t slots = (size_t)GPOOL_TABLES << GPOOL_BITS;
+    HIP_CHECK_RET(hipMalloc((void **)&p, slots * 8));
+    HIP_CHECK_RET(hipMalloc((void **)&lock, (GPOOL_TABLES + 4) * 4));
+    HIP_CHECK_RET(hipMemset(p, 0, slots * 8)); // generation 0 is never issued
+    HIP_CHECK_RET(hipMemset(lock, 0, (GPOOL_TABLES + 4) * 4));
+    h->gpool_lock = lock;
+    h->gpool_ctr = lock + GPOOL_TABLES;
+    h->gpool = p;
     return LEANN_OK;
 }
 
@@ -91,6 +90,8 @@ void leann_internal_free_graph(leann_backend *h) {
     (void)hipFree((void *)h->g.adjU);
     (void)hipFree((void *)h->g.upper_off);
     (void)hipFree(h->d_levels);
+    (void)hipFree(h->gpool);
+    (void)hipFree(h->gpool_lock);
 }
 
 extern "C" void leann_backend_close(leann_backend *h) {
@@ -98,7 +99,6 @@ extern "C" void leann_backend_close(leann_backend *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (auto *w : h->free_ws) ws_free(w);
-    for (auto &kv : h->stream_ws) ws_free(kv.second);
     leann_internal_free_graph(h);
     delete h;
 }
@@ -116,67 +116,57 @@ extern "C" int leann_backend_stats(const leann_backend *hc, leann_search_stats *
 }
 
 // ---- kernel dispatch --------------------------------------------------------------------------------
+// LDS visited table: 4 workgroups per CU are register-limited anyway, so 32 KiB (8192 slots) per
+// query is free; larger beams take 64 / 128 KiB.  A query that outgrows it moves to the HBM pool.
 static uint32_t pick_hash_bits(uint32_t ef) {
-    uint32_t want = ef * 64u, b = 10;
+    if (const char *e = getenv("LEANN_DEBUG_HASH_BITS")) { // test hook: force tiny tables to exercise the HBM pool
+        int v = atoi(e);
+        if (v >= 6 && v <= 15) return (uint32_t)v;
+    }
+    uint32_t want = ef * 64u, b = 13;
     while ((1u << b) < want && b < 15) b++;
     return b;
 }
 
 template <int T, int R>
-static int launch_search_T(const GraphView &g, SearchArgs a, Workspace *w, hipStream_t st) {
+static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t st) {
     constexpr int NW = 4;
     const uint32_t maxdeg = std::max(g.M0, g.M);
-    size_t lds1 = search_lds_bytes(a.ef, maxdeg, a.hash_bits, false);
-    size_t lds2 = search_lds_bytes(a.ef, maxdeg, GT_BITS, true);
-    if (lds1 > 160 * 1024) {
-        leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, lds1);
+    size_t lds = search_lds_bytes(a.ef, maxdeg, a.hash_bits);
+    if (lds > 160 * 1024) {
+        leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, lds);
         return LEANN_ERR_INVALID;
     }
-    if (lds1 > 64 * 1024)
-        HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_lds_kernel<T, R, NW>,
+    if (lds > 64 * 1024)
+        HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_kernel<T, R, NW>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_CHECK_RET(hipMemsetAsync(w->ctrs, 0, 16, st));
-    a.overflow_list = w->overflow_list;
-    a.overflow_count = w->ctrs;
-    hipLaunchKernelGGL((beam_search_lds_kernel<T, R, NW>), dim3(a.nq), dim3(NW * 64), lds1, st, g, a);
-    SearchArgs b = a;
-    b.q_map = w->overflow_list;
-    b.q_map_count = w->ctrs;
-    b.work_counter = w->ctrs + 1;
-    b.gtables = w->gtables;
-    b.hash_bits = GT_BITS;
-    hipLaunchKernelGGL((beam_search_gtable_kernel<T, R, NW>), dim3(GT_BLOCKS), dim3(NW * 64), lds2, st, g, b);
+    hipLaunchKernelGGL((beam_search_kernel<T, R, NW>), dim3(a.nq), dim3(NW * 64), lds, st, g, a);
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
 }
 
-int leann_internal_launch_search(const GraphView &g, SearchArgs a, Workspace *w, hipStream_t st) {
+int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st) {
     if (a.nq == 0) return LEANN_OK;
     if (a.ef < a.k) a.ef = a.k; // diskann.rs:54
     a.hash_bits = pick_hash_bits(a.ef);
-    int rc = ws_ensure(w, a.nq);
+    int rc = ensure_gpool(h);
     if (rc) return rc;
+    a.gpool = h->gpool;
+    a.gpool_lock = h->gpool_lock;
+    a.gpool_ctr = h->gpool_ctr;
+    const GraphView &g = h->g;
     int T = (int)((g.ld + 255) / 256);
     switch (T) {
-        case 1: return launch_search_T<1, 4>(g, a, w, st);
-        case 2: return launch_search_T<2, 4>(g, a, w, st);
-        case 3: return launch_search_T<3, 4>(g, a, w, st);
-        case 4: return launch_search_T<4, 3>(g, a, w, st);
-        case 5: case 6: return launch_search_T<6, 2>(g, a, w, st);
-        case 7: case 8: return launch_search_T<8, 2>(g, a, w, st);
+        case 1: return launch_search_T<1, 4>(g, a, st);
+        case 2: return launch_search_T<2, 4>(g, a, st);
+        case 3: return launch_search_T<3, 4>(g, a, st);
+        case 4: return launch_search_T<4, 3>(g, a, st);
+        case 5: case 6: return launch_search_T<6, 2>(g, a, st);
+        case 7: case 8: return launch_search_T<8, 2>(g, a, st);
         default:
             leann_set_error("search: dims %u > 2048 not supported", g.d);
             return LEANN_ERR_INVALID;
     }
-}
-
-Workspace *leann_internal_stream_ws(leann_backend *h, hipStream_t st) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    auto it = h->stream_ws.find(st);
-    if (it != h->stream_ws.end()) return it->second;
-    Workspace *w = new Workspace();
-    h->stream_ws[st] = w;
-    return w;
 }
 
 extern "C" int leann_backend_search_batch_device(const leann_backend *hc, const float *d_queries, size_t nq,
@@ -194,7 +184,6 @@ extern "C" int leann_backend_search_batch_device(const leann_backend *hc, const 
         HIP_CHECK_RET(hipMemsetAsync(d_counts, 0, nq * 4, st));
         return LEANN_OK;
     }
-    Workspace *w = leann_internal_stream_ws(h, st);
     SearchArgs a{};
     a.queries = d_queries;
     a.ldq = h->g.d;
@@ -207,7 +196,7 @@ extern "C" int leann_backend_search_batch_device(const leann_backend *hc, const 
     a.out_dists = d_dists;
     a.out_counts = d_counts;
     a.out_stats = d_stats;
-    return leann_internal_launch_search(h->g, a, w, st);
+    return leann_internal_launch_search(h, a, st);
 }
 
 // BackendSearcher::search batched over host pointers.
@@ -270,7 +259,7 @@ extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *
     a.out_dists = w->d_dists;
     a.out_counts = w->d_counts;
     a.out_stats = w->d_stats;
-    rc = leann_internal_launch_search(h->g, a, w, st);
+    rc = leann_internal_launch_search(h, a, st);
     if (rc) return fail(rc);
     std::vector<uint32_t> hstats(nq * 4);
     if (hipMemcpyAsync(keys, w->d_keys, no * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

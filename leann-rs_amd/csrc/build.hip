@@ -296,7 +296,6 @@ struct Builder {
     uint64_t *prop_key = nullptr, *prop_key2 = nullptr; uint32_t *prop_src = nullptr, *prop_src2 = nullptr;
     uint32_t *seg_start = nullptr, *nseg = nullptr;
     void *cub_tmp = nullptr; size_t cub_bytes = 0;
-    Workspace ws;
     hipStream_t st = nullptr;
 };
 
@@ -355,8 +354,7 @@ static int builder_alloc_scratch(Builder &b, size_t bmax) {
 }
 static void builder_free_scratch(Builder &b) {
     void *ps[] = {b.cand_keys, b.cand_d, b.cand_cnt, b.candU_keys, b.candU_d, b.candU_cnt, b.d_rowsU, b.prop_key, b.prop_key2,
-                  b.prop_src, b.prop_src2, b.seg_start, b.nseg, b.cub_tmp, b.d_order, b.adjd0, b.adjdU,
-                  b.ws.overflow_list, b.ws.ctrs, b.ws.gtables};
+                  b.prop_src, b.prop_src2, b.seg_start, b.nseg, b.cub_tmp, b.d_order, b.adjd0, b.adjdU};
     for (void *p : ps) (void)hipFree(p);
 }
 
@@ -396,7 +394,7 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
                 a.out_keys = b.candU_keys + offU * efc;
                 a.out_dists = b.candU_d + offU * efc;
                 a.out_counts = b.candU_cnt + offU;
-                int rc = leann_internal_launch_search(h->g, a, &b.ws, b.st);
+                int rc = leann_internal_launch_search(h, a, b.st);
                 if (rc) return rc;
                 jobs.push_back({l, (uint32_t)rows.size(), offU});
                 offU += rows.size();
@@ -412,7 +410,7 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
             a.out_keys = b.cand_keys;
             a.out_dists = b.cand_d;
             a.out_counts = b.cand_cnt;
-            int rc = leann_internal_launch_search(h->g, a, &b.ws, b.st);
+            int rc = leann_internal_launch_search(h, a, b.st);
             if (rc) return rc;
         }
         // ---- phase 2: select + link, level by level ---------------------------------------------

@@ -7,6 +7,9 @@
 // squared norm uses the same wave tree as every distance in the traversal kernel.
 #include "common.cuh"
 #include "../../include/leann_backend.h"
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #define TAG_P 0x50524F4A00000000ull
 #define TAG_C 0x43454E5400000000ull
@@ -104,10 +107,25 @@ extern "C" int leann_synth_rows_device(uint64_t seed, uint32_t dims, uint32_t ld
     hipStream_t st = (hipStream_t)stream;
     float *P = nullptr;
     if (r) {
-        HIP_CHECK_RET(hipMallocAsync((void **)&P, (size_t)r * ld * sizeof(float), st));
-        uint32_t total = r * ld;
-        hipLaunchKernelGGL(gen_projection_kernel, dim3((total + 255) / 256), dim3(256), 0, st, seed, dims, ld, r, P);
-        HIP_CHECK_RET(hipGetLastError());
+        // projection matrices are tiny (r x ld floats) and reused by every call with the same
+        // parameters: keep them for the life of the process (no stream-ordered allocator involved)
+        static std::mutex mu;
+        static std::map<std::tuple<int, uint64_t, uint32_t, uint32_t, uint32_t>, float *> cache;
+        int dev = 0;
+        HIP_CHECK_RET(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        auto key = std::make_tuple(dev, seed, dims, ld, r);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            HIP_CHECK_RET(hipMalloc((void **)&P, (size_t)r * ld * sizeof(float)));
+            uint32_t total = r * ld;
+            hipLaunchKernelGGL(gen_projection_kernel, dim3((total + 255) / 256), dim3(256), 0, st, seed, dims, ld, r, P);
+            HIP_CHECK_RET(hipGetLastError());
+            HIP_CHECK_RET(hipStreamSynchronize(st)); // other streams may use the cached matrix next
+            cache[key] = P;
+        } else {
+            P = it->second;
+        }
     }
     int T = (int)((ld + 255) / 256), rc;
     switch (T) {
@@ -118,6 +136,5 @@ extern "C" int leann_synth_rows_device(uint64_t seed, uint32_t dims, uint32_t ld
         case 5: case 6: rc = launch_gen<6>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
         default: rc = launch_gen<8>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
     }
-    if (P) HIP_CHECK_RET(hipFreeAsync(P, st));
     return rc;
 }

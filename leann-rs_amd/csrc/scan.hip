@@ -181,9 +181,9 @@ extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims
     float *S = nullptr;
     uint64_t *candA = nullptr, *candB = nullptr;
     size_t cand_len = std::max<size_t>(total_segs * k, k); // per query
-    HIP_CHECK_RET(hipMallocAsync((void **)&S, sizeof(float) * nq * std::max<size_t>(chunk, 1), st));
-    HIP_CHECK_RET(hipMallocAsync((void **)&candA, sizeof(uint64_t) * nq * cand_len, st));
-    HIP_CHECK_RET(hipMallocAsync((void **)&candB, sizeof(uint64_t) * nq * cand_len, st));
+    HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * nq * std::max<size_t>(chunk, 1)));
+    HIP_CHECK_RET(hipMalloc((void **)&candA, sizeof(uint64_t) * nq * cand_len));
+    HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
     HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
     size_t seg_off = 0;
     for (size_t c = 0; c < n_chunks; c++) {
@@ -211,9 +211,12 @@ extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims
     hipLaunchKernelGGL(finalize_scan_kernel, dim3((unsigned)nq), dim3(64), 0, st, src, (uint32_t)cand_len, (uint32_t)nq,
                        k, key_offset, d_keys, d_scores, d_counts);
     HIP_CHECK_RET(hipGetLastError());
-    HIP_CHECK_RET(hipFreeAsync(S, st));
-    HIP_CHECK_RET(hipFreeAsync(candA, st));
-    HIP_CHECK_RET(hipFreeAsync(candB, st));
+    // scratch is plain hipMalloc memory: wait for the stream before giving it back (this entry point
+    // is synchronous; the stream-ordered allocator proved unreliable on this stack)
+    HIP_CHECK_RET(hipStreamSynchronize(st));
+    HIP_CHECK_RET(hipFree(S));
+    HIP_CHECK_RET(hipFree(candA));
+    HIP_CHECK_RET(hipFree(candB));
     return LEANN_OK;
 }
 

@@ -26,26 +26,56 @@ struct GraphView {
     uint32_t d, ld, M, M0, max_level, entry;
 };
 
+// Pool of visited tables in HBM for the rare query whose LDS table fills up: GPOOL_TABLES tables of
+// 2^GPOOL_BITS u64 slots {generation:32 | id:32}.  Never cleared: a slot whose generation differs
+// from the owner's current one is empty.  Only atomics touch it, so hand-over between workgroups
+// on different XCDs needs no fence.
+#define GPOOL_TABLES 1024u
+#define GPOOL_BITS 16u
+
 struct SearchArgs {
     const float *queries;     // [nq x ldq] (ignored when q_rows != nullptr)
     const uint32_t *q_rows;   // optional: query i is base row q_rows[i] (index construction)
-    const uint32_t *q_map;    // optional: indirection list of query indices (overflow re-run)
-    const uint32_t *q_map_count;
     uint32_t ldq, nq, k, ef, target_level;
-    uint32_t hash_bits;       // visited table = 1 << hash_bits slots
+    uint32_t hash_bits;       // LDS visited table = 1 << hash_bits slots
     uint64_t key_offset;
     uint64_t *out_keys;       // [nq x k]
     float *out_dists;         // [nq x k]
     uint32_t *out_counts;     // [nq]
-    uint32_t *out_stats;      // [nq x 4] evals, hops0, hopsU, overflowed  (optional)
-    uint32_t *overflow_list;  // LDS-table pass: queries whose table filled up
-    uint32_t *overflow_count;
-    uint32_t *gtables;        // global-table pass: [gridDim.x x (1 << hash_bits)]
-    uint32_t *work_counter;   // global-table pass: persistent work queue head
+    uint32_t *out_stats;      // [nq x 4] evals, hops0, hopsU, 1 if the HBM table was used  (optional)
+    unsigned long long *gpool; // [GPOOL_TABLES << GPOOL_BITS]
+    uint32_t *gpool_lock;     // [GPOOL_TABLES] 0 = free
+    uint32_t *gpool_ctr;      // [0] acquire ticket, [1] generation counter
 };
 
 __device__ __forceinline__ uint32_t vis_hash(uint32_t id, uint32_t bits) {
     return (id * 0x9E3779B1u) >> (32 - bits);
+}
+
+__device__ __forceinline__ bool vis_insert_lds(uint32_t *tab, uint32_t bits, uint32_t id) {
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t h = vis_hash(id, bits);
+    for (;;) {
+        uint32_t old = atomicCAS(&tab[h], LEANN_EMPTY, id);
+        if (old == LEANN_EMPTY) return true;
+        if (old == id) return false;
+        h = (h + 1) & mask;
+    }
+}
+__device__ __forceinline__ bool vis_insert_hbm(unsigned long long *tab, uint32_t gen, uint32_t id) {
+    const uint32_t mask = (1u << GPOOL_BITS) - 1u;
+    uint32_t h = vis_hash(id, GPOOL_BITS);
+    const unsigned long long mine = ((unsigned long long)gen << 32) | id;
+    for (;;) {
+        unsigned long long cur = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(cur >> 32) != gen) { // stale generation == empty
+            unsigned long long prev = atomicCAS(&tab[h], cur, mine);
+            if (prev == cur) return true;
+            continue; // somebody of this workgroup took the slot: look at it again
+        }
+        if ((uint32_t)cur == id) return false;
+        h = (h + 1) & mask;
+    }
 }
 
 // ---- distance of up to R rows per wave, all loads issued before the first use -----------------
@@ -76,20 +106,18 @@ __device__ __forceinline__ void wave_dist_rows(const float4 (&q)[T], const float
 struct SearchLds {
     uint64_t *s_key;
     uint32_t *s_new;
-    uint32_t *misc;  // [0]=n_new [1],[2]=next selection (double buffered) [3]=abort
+    uint32_t *misc;  // [0]=n_new [1],[2]=next selection (double buffered) [3]=table full [4]=pool slot [5]=generation
     uint32_t *table; // LDS table (nullptr for the global variant)
 };
-__host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits, bool gtable) {
+__host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits) {
     size_t efp = (ef + 1) & ~1u;
     size_t b = 2 * efp * 8 + (size_t)maxdeg * 8 + (size_t)maxdeg * 4 + 16 * 4;
     b = (b + 15) & ~(size_t)15;
-    if (!gtable) b += ((size_t)1 << hash_bits) * 4;
-    return b;
+    return b + ((size_t)1 << hash_bits) * 4;
 }
 
-template <int T, int R, int NW, bool GTABLE>
-__device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_t qi, unsigned char *smem,
-                                uint32_t *gtable) {
+template <int T, int R, int NW>
+__device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_t qi, unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ef = a.ef;
     const uint32_t maxdeg = g.M0 > g.M ? g.M0 : g.M;
@@ -101,9 +129,12 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     s.misc = s.s_new + maxdeg;
     size_t off = 2 * (size_t)efp * 8 + (size_t)maxdeg * 12 + 64;
     off = (off + 15) & ~(size_t)15;
-    uint32_t *table = GTABLE ? gtable : reinterpret_cast<uint32_t *>(smem + off);
-    const uint32_t hbits = a.hash_bits, hsize = 1u << hbits, hmask = hsize - 1;
-    const uint32_t vis_limit = hsize - (hsize >> 2); // 75 % load
+    uint32_t *table = reinterpret_cast<uint32_t *>(smem + off);
+    const uint32_t hbits = a.hash_bits, hsize = 1u << hbits;
+    uint32_t vis_limit = hsize - (hsize >> 2); // 75 % load
+    bool hbm = false;                 // visited set lives in the HBM pool table (after an overflow)
+    unsigned long long *gtab = nullptr;
+    uint32_t gslot = 0, gen = 0;
 
     // ---- query into registers -----------------------------------------------------------------
     float4 q[T];
@@ -132,16 +163,24 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     for (int lv = (int)g.max_level; lv >= (int)a.target_level; --lv) {
         const uint32_t ef_l = (lv == (int)a.target_level) ? ef : 1u;
         const uint32_t deg = lv == 0 ? g.M0 : g.M;
-        for (uint32_t i = tid; i < hsize; i += NW * 64) table[i] = LEANN_EMPTY;
+        if (!hbm)
+            for (uint32_t i = tid; i < hsize; i += NW * 64) table[i] = LEANN_EMPTY;
         __syncthreads();
         if (tid == 0) {
             W0[0] = best;
-            table[vis_hash(key_id(best), hbits)] = key_id(best);
+            if (hbm) {
+                gen = atomicAdd(&a.gpool_ctr[1], 1u) + 1u;
+                s.misc[5] = gen;
+                vis_insert_hbm(gtab, gen, key_id(best));
+            } else {
+                table[vis_hash(key_id(best), hbits)] = key_id(best);
+            }
             s.misc[1] = LEANN_EMPTY;
             s.misc[2] = LEANN_EMPTY;
             s.misc[3] = 0;
         }
         __syncthreads();
+        if (hbm) gen = s.misc[5];
         cur = 0;
         wsize = 1;
         n_vis = 1;
@@ -160,15 +199,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     for (uint32_t base = 0; base < deg; base += 64) {
                         uint32_t e = (base + lane < deg) ? adj[base + lane] : LEANN_EMPTY;
                         bool isnew = false;
-                        if (e != LEANN_EMPTY) {
-                            uint32_t h = vis_hash(e, hbits);
-                            for (;;) {
-                                uint32_t old = atomicCAS(&table[h], LEANN_EMPTY, e);
-                                if (old == LEANN_EMPTY) { isnew = true; break; }
-                                if (old == e) break;
-                                h = (h + 1) & hmask;
-                            }
-                        }
+                        if (e != LEANN_EMPTY) isnew = hbm ? vis_insert_hbm(gtab, gen, e) : vis_insert_lds(table, hbits, e);
                         unsigned long long m = __ballot(isnew);
                         uint32_t pos = n_new + __popcll(m & ((1ull << lane) - 1ull));
                         if (isnew) s.s_new[pos] = e;
@@ -177,7 +208,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 }
                 n_vis += n_new;
                 n_evals += n_new;
-                if (lv == 0) hops0++; else hopsU++;
+                if (!ovf) { if (lv == 0) hops0++; else hopsU++; }
                 if (lane == 0) {
                     s.misc[0] = n_new;
                     s.misc[1 + (hop & 1)] = LEANN_EMPTY; // slot THIS hop's merge mins into (last read two hops ago)
@@ -185,7 +216,35 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 }
             }
             __syncthreads(); // B1
-            if (s.misc[3]) { aborted = true; break; }
+            const uint32_t table_full = s.misc[3];
+            if (table_full) {
+                if (hbm) { aborted = true; break; } // even the 2^16-slot HBM table is 75 % full
+                // LDS table full: move the visited set to a pooled HBM table and redo this hop
+                __syncthreads(); // every thread has read the flag before it is cleared
+                if (tid == 0) {
+                    uint32_t t = atomicAdd(&a.gpool_ctr[0], 1u), slot;
+                    for (uint32_t i = 0;; i++) {
+                        slot = (t + i) % GPOOL_TABLES;
+                        if (atomicCAS(&a.gpool_lock[slot], 0u, 1u) == 0u) break;
+                        if ((i % GPOOL_TABLES) == GPOOL_TABLES - 1) __builtin_amdgcn_s_sleep(32);
+                    }
+                    s.misc[4] = slot;
+                    s.misc[5] = atomicAdd(&a.gpool_ctr[1], 1u) + 1u;
+                    s.misc[3] = 0;
+                }
+                __syncthreads();
+                gslot = s.misc[4];
+                gen = s.misc[5];
+                gtab = a.gpool + ((size_t)gslot << GPOOL_BITS);
+                for (uint32_t i = tid; i < hsize; i += NW * 64) {
+                    uint32_t e = table[i];
+                    if (e != LEANN_EMPTY) vis_insert_hbm(gtab, gen, e);
+                }
+                hbm = true;
+                vis_limit = (1u << GPOOL_BITS) - (1u << (GPOOL_BITS - 2));
+                __syncthreads();
+                continue;
+            }
             const uint32_t n_new = s.misc[0];
             // ---- phase C: stream the new rows, R in flight per wave ------------------------------
             for (uint32_t j0 = wave; j0 < n_new; j0 += NW * R) {
@@ -244,23 +303,22 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     }
 
     // ---- results ------------------------------------------------------------------------------
-    if (aborted) {
-        if (!GTABLE) {
-            if (tid == 0) {
-                uint32_t slot = atomicAdd(a.overflow_count, 1u);
-                a.overflow_list[slot] = qi;
-            }
-        } else { // even the 2^20-slot table filled up: report an empty result, flagged in the stats
-            for (uint32_t t = tid; t < a.k; t += NW * 64) {
-                a.out_keys[(size_t)qi * a.k + t] = 0xFFFFFFFFFFFFFFFFull;
-                a.out_dists[(size_t)qi * a.k + t] = __uint_as_float(0x7F800000u);
-            }
-            if (tid == 0) {
-                a.out_counts[qi] = 0;
-                if (a.out_stats) a.out_stats[(size_t)qi * 4 + 3] = 2u;
+    __syncthreads();
+    if (hbm && tid == 0) atomicExch(&a.gpool_lock[gslot], 0u); // every probe of this workgroup has returned
+    if (aborted) { // pathological: > 49152 distinct nodes visited on one level; report an empty result
+        for (uint32_t t = tid; t < a.k; t += NW * 64) {
+            a.out_keys[(size_t)qi * a.k + t] = 0xFFFFFFFFFFFFFFFFull;
+            a.out_dists[(size_t)qi * a.k + t] = __uint_as_float(0x7F800000u);
+        }
+        if (tid == 0) {
+            a.out_counts[qi] = 0;
+            if (a.out_stats) {
+                a.out_stats[(size_t)qi * 4 + 0] = n_evals;
+                a.out_stats[(size_t)qi * 4 + 1] = hops0;
+                a.out_stats[(size_t)qi * 4 + 2] = hopsU;
+                a.out_stats[(size_t)qi * 4 + 3] = 2u;
             }
         }
-        __syncthreads();
         return;
     }
     const uint32_t nout = min(wsize, a.k);
@@ -282,34 +340,17 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
             a.out_stats[(size_t)qi * 4 + 0] = n_evals;
             a.out_stats[(size_t)qi * 4 + 1] = hops0;
             a.out_stats[(size_t)qi * 4 + 2] = hopsU;
-            a.out_stats[(size_t)qi * 4 + 3] = GTABLE ? 1u : 0u;
+            a.out_stats[(size_t)qi * 4 + 3] = hbm ? 1u : 0u;
         }
     }
     __syncthreads();
 }
 
-// One workgroup per query; visited table in LDS.
+// One workgroup per query.
 template <int T, int R, int NW>
-__global__ void __launch_bounds__(NW * 64) beam_search_lds_kernel(GraphView g, SearchArgs a) {
+__global__ void __launch_bounds__(NW * 64) beam_search_kernel(GraphView g, SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t qi = blockIdx.x;
     if (qi >= a.nq) return;
-    beam_search_one<T, R, NW, false>(g, a, qi, smem, nullptr);
-}
-
-// Overflow re-run: a few persistent workgroups drain the overflow list with a big table in HBM.
-template <int T, int R, int NW>
-__global__ void __launch_bounds__(NW * 64) beam_search_gtable_kernel(GraphView g, SearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t s_item;
-    const uint32_t total = *a.q_map_count;
-    uint32_t *gt = a.gtables + ((size_t)blockIdx.x << a.hash_bits);
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(a.work_counter, 1u);
-        __syncthreads();
-        uint32_t item = s_item;
-        __syncthreads();
-        if (item >= total) break; // uniform exit: every wave leaves on the same item
-        beam_search_one<T, R, NW, true>(g, a, a.q_map[item], smem, gt);
-    }
+    beam_search_one<T, R, NW>(g, a, qi, smem);
 }

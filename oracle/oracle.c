@@ -80,26 +80,60 @@ float orc_dot_canon_ref(const float *a, const float *b, uint32_t d) {
         for (int i = 0; i < w; i++) acc[i] = acc[2 * i] + acc[2 * i + 1];
     return acc[0];
 }
+/* AVX2/FMA form of the same definition: the 256 strided accumulators live in two banks of 16 ymm
+ * registers; the adjacent-pair tree is three hadd levels inside each group of four registers
+ * (levels 1-3), then 128-bit hadds (levels 4-8).  Bit-identical to orc_dot_canon_ref (tested). */
+#include <immintrin.h>
 float orc_dot_canon(const float *a, const float *b, uint32_t d) {
-    float acc[256] __attribute__((aligned(64)));
-    uint32_t full = d & ~255u;
-    if (full == 0) {
-        for (int i = 0; i < 256; i++) acc[i] = 0.0f;
-    } else {
-        for (int i = 0; i < 256; i++) acc[i] = fmaf(a[i], b[i], 0.0f);
-        for (uint32_t t = 256; t < full; t += 256)
-            for (int i = 0; i < 256; i++) acc[i] = fmaf(a[t + i], b[t + i], acc[i]);
+    float acc[256] __attribute__((aligned(32)));
+    const uint32_t full = d & ~255u;
+    for (int h = 0; h < 2; h++) {
+        __m256 v[16];
+        for (int i = 0; i < 16; i++) v[i] = _mm256_setzero_ps();
+        for (uint32_t t = 0; t < full; t += 256) {
+            const float *pa = a + t + 128 * h, *pb = b + t + 128 * h;
+            for (int i = 0; i < 16; i++)
+                v[i] = _mm256_fmadd_ps(_mm256_loadu_ps(pa + 8 * i), _mm256_loadu_ps(pb + 8 * i), v[i]);
+        }
+        for (int i = 0; i < 16; i++) _mm256_store_ps(acc + 128 * h + 8 * i, v[i]);
     }
     for (uint32_t j = full; j < d; j++) acc[j - full] = fmaf(a[j], b[j], acc[j - full]);
-    float t1[128] __attribute__((aligned(64)));
-    for (int i = 0; i < 128; i++) t1[i] = acc[2 * i] + acc[2 * i + 1];
-    for (int i = 0; i < 64; i++) acc[i] = t1[2 * i] + t1[2 * i + 1];
-    for (int i = 0; i < 32; i++) t1[i] = acc[2 * i] + acc[2 * i + 1];
-    for (int i = 0; i < 16; i++) acc[i] = t1[2 * i] + t1[2 * i + 1];
-    for (int i = 0; i < 8; i++) t1[i] = acc[2 * i] + acc[2 * i + 1];
-    for (int i = 0; i < 4; i++) acc[i] = t1[2 * i] + t1[2 * i + 1];
-    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __m128 s[8];
+    for (int g = 0; g < 8; g++) {
+        __m256 A = _mm256_load_ps(acc + 32 * g), B = _mm256_load_ps(acc + 32 * g + 8);
+        __m256 C = _mm256_load_ps(acc + 32 * g + 16), D = _mm256_load_ps(acc + 32 * g + 24);
+        __m256 r = _mm256_hadd_ps(_mm256_hadd_ps(A, B), _mm256_hadd_ps(C, D));
+        s[g] = _mm_add_ps(_mm256_castps256_ps128(r), _mm256_extractf128_ps(r, 1));
+    }
+    __m128 t0 = _mm_hadd_ps(s[0], s[1]), t1 = _mm_hadd_ps(s[2], s[3]);
+    __m128 t2 = _mm_hadd_ps(s[4], s[5]), t3 = _mm_hadd_ps(s[6], s[7]);
+    __m128 u0 = _mm_hadd_ps(t0, t1), u1 = _mm_hadd_ps(t2, t3);
+    __m128 w = _mm_hadd_ps(u0, u1);
+    w = _mm_hadd_ps(w, w);
+    w = _mm_hadd_ps(w, w);
+    return _mm_cvtss_f32(w);
 }
+/* Plain 4-accumulator AVX2 dot (what a SIMD library such as usearch's would do).  NOT bit-compatible
+ * with the GPU; used only when timing the CPU baseline (orc_set_fast_dot(1)), never for parity. */
+float orc_dot_fast(const float *a, const float *b, uint32_t d) {
+    __m256 s0 = _mm256_setzero_ps(), s1 = s0, s2 = s0, s3 = s0;
+    uint32_t j = 0;
+    for (; j + 32 <= d; j += 32) {
+        s0 = _mm256_fmadd_ps(_mm256_loadu_ps(a + j), _mm256_loadu_ps(b + j), s0);
+        s1 = _mm256_fmadd_ps(_mm256_loadu_ps(a + j + 8), _mm256_loadu_ps(b + j + 8), s1);
+        s2 = _mm256_fmadd_ps(_mm256_loadu_ps(a + j + 16), _mm256_loadu_ps(b + j + 16), s2);
+        s3 = _mm256_fmadd_ps(_mm256_loadu_ps(a + j + 24), _mm256_loadu_ps(b + j + 24), s3);
+    }
+    s0 = _mm256_add_ps(_mm256_add_ps(s0, s1), _mm256_add_ps(s2, s3));
+    __m128 x = _mm_add_ps(_mm256_castps256_ps128(s0), _mm256_extractf128_ps(s0, 1));
+    x = _mm_hadd_ps(x, x);
+    x = _mm_hadd_ps(x, x);
+    float r = _mm_cvtss_f32(x);
+    for (; j < d; j++) r += a[j] * b[j];
+    return r;
+}
+static int g_fast_dot = 0;
+void orc_set_fast_dot(int on) { g_fast_dot = on; }
 /* src/index/recompute.rs:137-139 — a.iter().zip(b).map(|(x,y)| x*y).sum(): product rounded,
  * then added left to right starting from 0.0 (f32 Sum), stops at the shorter length. */
 float orc_dot_seq(const float *a, const float *b, uint32_t d) {
@@ -225,6 +259,7 @@ static inline const uint32_t *nbrs(const orc_graph *g, uint32_t node, uint32_t l
     return g->adjU + ((size_t)g->upper_off[node] + (level - 1)) * g->M;
 }
 static inline float gdist(const orc_graph *g, const float *q, uint32_t id) {
+    if (g_fast_dot) return 1.0f - orc_dot_fast(q, g->X + (size_t)id * g->ld, g->d);
     return 1.0f - orc_dot_canon(q, g->X + (size_t)id * g->ld, g->d);
 }
 

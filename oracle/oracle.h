@@ -52,6 +52,8 @@ float orc_dot_canon(const float *a, const float *b, uint32_t d);     /* wave ord
 float orc_dot_canon_ref(const float *a, const float *b, uint32_t d); /* same, scalar definition */
 float orc_dot_seq(const float *a, const float *b, uint32_t d);       /* recompute.rs:137-139 literal */
 float orc_dot_seqfma(const float *a, const float *b, uint32_t d);    /* k-ordered fmaf chain (MFMA f32 order) */
+float orc_dot_fast(const float *a, const float *b, uint32_t d);      /* plain AVX2 dot; CPU-baseline timing only */
+void orc_set_fast_dot(int on);                                      /* graph search uses orc_dot_fast (timing only) */
 
 uint32_t orc_f32_orderable(float f);
 float orc_orderable_f32(uint32_t u);

@@ -38,7 +38,8 @@ def lib():
         L.orc_hash3.argtypes = [C.c_uint64] * 3
         L.orc_gen_rows.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                    C.c_uint32, C.c_uint64, C.c_uint64, f32p]
-        for n in ("orc_dot_canon", "orc_dot_canon_ref", "orc_dot_seq", "orc_dot_seqfma"):
+        L.orc_set_fast_dot.argtypes = [C.c_int]
+        for n in ("orc_dot_canon", "orc_dot_canon_ref", "orc_dot_seq", "orc_dot_seqfma", "orc_dot_fast"):
             f = getattr(L, n)
             f.restype = C.c_float
             f.argtypes = [f32p, f32p, C.c_uint32]

@@ -97,17 +97,24 @@ def test_tiny_and_short_results(la, po, gpu):
     s.close()
 
 
-def test_visited_table_overflow_rerun(la, po, gpu):
-    """ef=16 gives a 1024-slot LDS table; a dense graph overflows it and the query is re-run with the
-    HBM table — results must not change."""
+def test_visited_table_overflow_moves_to_hbm_pool(la, po, gpu, monkeypatch):
+    """A query whose LDS visited table fills up migrates to a pooled HBM table mid-search; results
+    and counters must not change.  LEANN_DEBUG_HASH_BITS forces a 256-slot LDS table."""
     n, d, M = 6000, 128, 32
     X = synth(po, n, d, r=0)  # i.i.d.: searches wander
-    Q = synth(po, 32, d, stream=1, r=0)
+    Q = synth(po, 300, d, stream=1, r=0)
     G = po.Graph.build_hnsw(X, M=M, efc=32)
     lv, uo, a0, aU = G.export()
     s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, M, 2 * M, G.max_level, G.entry, lv, uo, a0, aU)
+    monkeypatch.setenv("LEANN_DEBUG_HASH_BITS", "8")
     _assert_same(po, G, s, Q, 10, 16)
-    assert s.stats()["n_table_overflow"] > 0
+    assert s.stats()["n_table_overflow"] == len(Q)
+    monkeypatch.setenv("LEANN_DEBUG_HASH_BITS", "11")
+    _assert_same(po, G, s, Q, 10, 64)
+    assert 0 < s.stats()["n_table_overflow"] <= len(Q)
+    monkeypatch.delenv("LEANN_DEBUG_HASH_BITS")
+    _assert_same(po, G, s, Q, 10, 64)
+    assert s.stats()["n_table_overflow"] == 0
     s.close()
 
 
