@@ -87,6 +87,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
 
     import leann_rs_amd as la  # after torch: binds to the HIP runtime torch already loaded
+    from leann_rs_amd.shard import exchange_topk, _hip_merge as hip_merge
     L, chk = la.lib(), la._native.check
 
     def log(*a):
@@ -130,16 +131,6 @@ def main():
     dists = torch.empty((B, k), dtype=torch.float32, device=dev)
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
     stats = torch.zeros((n_pool, B, 4), dtype=torch.int32, device=dev)
-    if shard:
-        pack = torch.empty((B, k, 3), dtype=torch.int32, device=dev)       # [key lo, key hi, dist bits]
-        gathered = torch.empty((world, B, k, 3), dtype=torch.int32, device=dev)
-        g_keys = torch.empty((world, B, k), dtype=torch.int64, device=dev)
-        g_dists = torch.empty((world, B, k), dtype=torch.float32, device=dev)
-        g_counts = torch.empty((world, B), dtype=torch.int32, device=dev)
-        cnt_all = torch.empty((world, B), dtype=torch.int32, device=dev)
-        m_keys = torch.empty((B, k), dtype=torch.int64, device=dev)
-        m_dists = torch.empty((B, k), dtype=torch.float32, device=dev)
-        m_counts = torch.empty((B,), dtype=torch.int32, device=dev)
     stream.synchronize()
 
     def search(step, timed_events=None):
@@ -153,17 +144,10 @@ def main():
         if timed_events is not None:
             timed_events[1].record(stream)
         if shard:
-            # exchange step: all-gather {keys, dists, counts} of every shard, then merge on every rank
+            # exchange step (leann-rs_amd/shard.py): all-gather the per-shard lists over RCCL, merge on every rank
             with torch.cuda.stream(stream):
-                pack[..., 0:2] = keys.view(torch.int32).view(B, k, 2)
-                pack[..., 2] = dists.view(torch.int32)
-                dist.all_gather_into_tensor(gathered, pack)
-                dist.all_gather_into_tensor(cnt_all, counts)
-                g_keys.copy_(gathered[..., 0:2].contiguous().view(torch.int64).view(world, B, k))
-                g_dists.copy_(gathered[..., 2].contiguous().view(torch.float32))
-                g_counts.copy_(cnt_all)
-                chk(L.leann_merge_topk_device(g_keys.data_ptr(), g_dists.data_ptr(), g_counts.data_ptr(), world, B, k, k,
-                                              0, m_keys.data_ptr(), m_dists.data_ptr(), m_counts.data_ptr(), sp))
+                g_keys, g_dists, g_counts = exchange_topk(keys, dists, counts, world)
+                m_keys, _, _ = hip_merge(g_keys, g_dists, g_counts, k, False, stream.cuda_stream)
             return m_keys
         return keys
 
@@ -177,15 +161,9 @@ def main():
                                  gt_s.data_ptr(), gt_c.data_ptr(), sp))
     stream.synchronize()
     if shard:  # global truth = merge of per-shard exact lists (scores descending)
-        gk = torch.empty((world, nrq, k), dtype=torch.int64, device=dev)
-        gs = torch.empty((world, nrq, k), dtype=torch.float32, device=dev)
-        gc = torch.empty((world, nrq), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(gk, gt_k)
-        dist.all_gather_into_tensor(gs, gt_s)
-        dist.all_gather_into_tensor(gc, gt_c)
-        torch.cuda.synchronize()
-        chk(L.leann_merge_topk_device(gk.data_ptr(), gs.data_ptr(), gc.data_ptr(), world, nrq, k, k, 1, gt_k.data_ptr(),
-                                      gt_s.data_ptr(), gt_c.data_ptr(), sp))
+        with torch.cuda.stream(stream):
+            gk, gs, gc = exchange_topk(gt_k, gt_s, gt_c, world)
+            gt_k, gt_s, gt_c = hip_merge(gk, gs, gc, k, True, stream.cuda_stream)
         stream.synchronize()
     log(f"exact ground truth for {nrq} queries in {time.time() - t0:.2f}s")
     found = search(0)

@@ -7,3 +7,10 @@ from ._native import LeannError, lib, device_count, LIB_PATH  # noqa: F401
 from .backend import (BackendBuilder, BackendSearcher, BackendType, DiskAnnSearcher,  # noqa: F401
                       HnswSearcher)
 from .device import DeviceArray, sync  # noqa: F401
+
+
+def __getattr__(name):  # torch is only needed for the multi-GPU helpers: import them lazily
+    if name in ("ShardedSearcher", "shard_range", "exchange_topk"):
+        from . import shard
+        return getattr(shard, name)
+    raise AttributeError(name)

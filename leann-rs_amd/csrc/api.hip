@@ -137,10 +137,17 @@ static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t 
         leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, lds);
         return LEANN_ERR_INVALID;
     }
-    if (lds > 64 * 1024)
-        HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_kernel<T, R, NW>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((beam_search_kernel<T, R, NW>), dim3(a.nq), dim3(NW * 64), lds, st, g, a);
+    if (a.q_rows) {
+        if (lds > 64 * 1024)
+            HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_kernel<T, R, NW, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((beam_search_kernel<T, R, NW, true>), dim3(a.nq), dim3(NW * 64), lds, st, g, a);
+    } else {
+        if (lds > 64 * 1024)
+            HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_kernel<T, R, NW, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((beam_search_kernel<T, R, NW, false>), dim3(a.nq), dim3(NW * 64), lds, st, g, a);
+    }
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
 }

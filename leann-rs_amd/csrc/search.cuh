@@ -346,8 +346,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     __syncthreads();
 }
 
-// One workgroup per query.
-template <int T, int R, int NW>
+// One workgroup per query.  BUILD only names the instantiation used by index construction (queries are
+// base rows, k = ef) so that profiles keep query launches and construction launches apart.
+template <int T, int R, int NW, bool BUILD>
 __global__ void __launch_bounds__(NW * 64) beam_search_kernel(GraphView g, SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t qi = blockIdx.x;
