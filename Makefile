@@ -8,7 +8,10 @@ HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HDRS     := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) include/leann_backend.h
 
-all: $(CSRC)/libleann_hip.so oracle
+HOST     := leann-rs_amd/host
+CXXFLAGS := -O2 -std=c++17 -ffp-contract=off -Wall -Wextra -Wno-unused-parameter
+
+all: $(CSRC)/libleann_hip.so oracle $(HOST)/leann $(HOST)/host_selftest
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -16,11 +19,18 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 $(CSRC)/libleann_hip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
 
+# C++ host mirror of the reference's index layer + `leann search` CLI (links only the C ABI)
+$(HOST)/leann: $(HOST)/leann_cli.cpp $(HOST)/leann_host.hpp $(HOST)/json.hpp include/leann_backend.h $(CSRC)/libleann_hip.so
+	g++ $(CXXFLAGS) -o $@ $(HOST)/leann_cli.cpp -L$(CSRC) -lleann_hip -Wl,-rpath,'$$ORIGIN/../csrc' -Wl,-rpath,/opt/rocm/lib
+
+$(HOST)/host_selftest: $(HOST)/host_selftest.cpp $(HOST)/leann_host.hpp $(HOST)/json.hpp include/leann_backend.h $(CSRC)/libleann_hip.so
+	g++ $(CXXFLAGS) -o $@ $(HOST)/host_selftest.cpp -L$(CSRC) -lleann_hip -Wl,-rpath,'$$ORIGIN/../csrc' -Wl,-rpath,/opt/rocm/lib
+
 oracle:
 	$(MAKE) -s -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o $(CSRC)/*.so
+	rm -f $(CSRC)/*.o $(CSRC)/*.so $(HOST)/leann $(HOST)/host_selftest
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,103 @@
+"""-m gpu: `leann build` + `leann search` end to end through the C++ host (IndexSearcher,
+RecomputeSearcher, hybrid, filter, output formats of src/cli/search.rs:211-256)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "leann-rs_amd", "host", "leann")
+
+TOPICS = ["rust ownership borrow checker lifetimes", "python asyncio event loop coroutine", "vector database embedding search",
+          "graph traversal beam hnsw neighbours", "gpu kernel wavefront lds bandwidth", "bm25 ranking term frequency"]
+
+
+def _docs(n):
+    out = []
+    for i in range(n):
+        t = TOPICS[i % len(TOPICS)]
+        out.append(dict(id=str(i + 1), text=f"passage {i} about {t} number {i * 7919 % 1000}",
+                        metadata=dict(source=f"file{i % 10}.{'rs' if i % 2 else 'py'}", lines=i)))
+    return out
+
+
+def _run(*args, cwd=None):
+    return subprocess.run([EXE, *args], capture_output=True, text=True, cwd=cwd)
+
+
+@pytest.fixture(scope="module")
+def index_dir(tmp_path_factory, gpu):
+    d = tmp_path_factory.mktemp("cli")
+    docs = _docs(600)
+    (d / "docs.jsonl").write_text("\n".join(json.dumps(x) for x in docs))
+    r = _run("build", "--index-dir", str(d / "idx"), "--passages-jsonl", str(d / "docs.jsonl"), "--dimensions", "96",
+             "--graph-degree", "16", "--complexity", "64")
+    assert r.returncode == 0, r.stderr
+    r = _run("build", "--index-dir", str(d / "pruned"), "--passages-jsonl", str(d / "docs.jsonl"), "--dimensions", "96", "--pruned")
+    assert r.returncode == 0, r.stderr
+    return d
+
+
+def test_index_directory_layout(index_dir):
+    files = set(os.listdir(index_dir / "idx"))
+    # src/index layout: stem documents.leann -> extension replaced (searcher.rs:83, passages.rs:48-49, embeddings.rs:42-44)
+    assert {"documents.leann.meta.json", "documents.index", "documents.ids.txt", "documents.passages.jsonl",
+            "documents.passages.idx.json", "documents.embeddings"} <= files
+    meta = json.loads((index_dir / "idx" / "documents.leann.meta.json").read_text())
+    assert meta["backend_name"] == "hnsw" and meta["dimensions"] == 96 and meta["passage_count"] == 600
+    assert os.path.getsize(index_dir / "idx" / "documents.embeddings") == 600 * 96 * 4
+    assert "documents.index" not in os.listdir(index_dir / "pruned")  # pruned: no ANN index, recompute at query time
+
+
+def test_search_json_and_text(index_dir):
+    q = "graph traversal beam hnsw neighbours with extra words"
+    r = _run("search", q, "-i", str(index_dir / "idx"), "--top-k", "5", "--format", "json")
+    assert r.returncode == 0, r.stderr
+    res = json.loads(r.stdout)
+    assert len(res) == 5 and list(res[0].keys()) == ["id", "metadata", "score", "text"]  # sorted keys, like serde_json
+    assert all("hnsw" in x["text"] for x in res)
+    scores = [x["score"] for x in res]
+    assert scores == sorted(scores)  # backend distance, ascending
+    r = _run("search", q, "-i", str(index_dir / "idx"), "--top-k", "3", "--show-metadata")
+    assert r.returncode == 0
+    assert f"Search results for '{q}' (top 3):" in r.stdout and "1. Score: " in r.stdout and "   Source: " in r.stdout
+    # text scores are the json scores to 4 decimals
+    first = float(r.stdout.split("1. Score: ")[1].split("\n")[0])
+    assert abs(first - scores[0]) < 5e-5
+
+
+def test_filter_and_hybrid(index_dir):
+    q = "bm25 ranking term frequency and more words"
+    r = _run("search", q, "-i", str(index_dir / "idx"), "--top-k", "4", "--format", "json", "-f", "source:*.rs")
+    res = json.loads(r.stdout)
+    assert len(res) == 4 and all(x["metadata"]["source"].endswith(".rs") for x in res)
+    # 3-word query -> auto hybrid (search.rs:147-148): scores become blended, descending, in [0, 1]
+    r = _run("search", "bm25 ranking frequency", "-i", str(index_dir / "idx"), "--top-k", "5", "--format", "json")
+    res = json.loads(r.stdout)
+    sc = [x["score"] for x in res]
+    assert len(res) == 5 and sc == sorted(sc, reverse=True) and 0.0 <= min(sc) and max(sc) <= 1.0 + 1e-6
+    r2 = _run("search", "bm25 ranking frequency", "-i", str(index_dir / "idx"), "--top-k", "5", "--format", "json",
+              "--auto-hybrid", "false")
+    sc2 = [x["score"] for x in json.loads(r2.stdout)]
+    assert sc2 == sorted(sc2)  # plain vector search again
+
+
+def test_pruned_index_uses_recompute_search(index_dir):
+    q = "gpu kernel wavefront lds bandwidth for the win"
+    r = _run("search", q, "-i", str(index_dir / "pruned"), "--top-k", "6", "--format", "json")
+    assert r.returncode == 0, r.stderr
+    res = json.loads(r.stdout)
+    sc = [x["score"] for x in res]
+    assert len(res) == 6 and sc == sorted(sc, reverse=True)  # raw dot product, descending (recompute.rs:99-106)
+    assert all("wavefront" in x["text"] for x in res)
+    # same ranking as exact search over the stored embeddings of the un-pruned twin
+    emb = np.fromfile(index_dir / "idx" / "documents.embeddings", np.float32).reshape(600, 96)
+    r2 = _run("search", q, "-i", str(index_dir / "idx"), "--top-k", "6", "--format", "json", "--complexity", "600")
+    ids_ann = [x["id"] for x in json.loads(r2.stdout)]
+    assert [x["id"] for x in res] == ids_ann
+    # and score == 1 - distance within 1e-5
+    d = [x["score"] for x in json.loads(r2.stdout)]
+    assert np.allclose(np.array(sc), 1.0 - np.array(d), atol=1e-5)
