@@ -138,6 +138,29 @@ int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims, size_t ld
                            const uint8_t *d_allow_mask, uint64_t key_offset, uint64_t *d_keys,
                            float *d_scores, uint32_t *d_counts, void *stream);
 
+/* ---- recompute search ("pruned" index, no stored vectors) -----------------------------------------
+ * RecomputeSearcher::search(query_embedding, embedding_provider, top_k, filter)
+ * src/index/recompute.rs:52-123 with the provider (src/embedding/mod.rs:112-120; dense + L2-normalise
+ * tail of src/embedding/candle.rs:165,218-225) resident on the device:
+ *     features [n x h] bf16 (borrowed), weights [h x dims] bf16 (copied, re-tiled),
+ *     embedding_i = l2_normalize(W^T f_i)  (bf16 MFMA, f32 accumulate)
+ * scores = raw dot product, descending, ties -> lower position; allow_mask = early filter (:66-71). */
+typedef struct leann_recompute leann_recompute;
+int leann_recompute_create(const uint16_t *d_features, size_t n, size_t h, const uint16_t *d_weights,
+                           size_t dims, int device, uint64_t key_offset, leann_recompute **out);
+int leann_recompute_search_batch_device(const leann_recompute *r, const float *d_queries, size_t nq,
+                                        size_t top_k, const uint8_t *d_allow_mask, uint64_t *d_keys,
+                                        float *d_scores, uint32_t *d_counts, void *stream);
+/* materialise embeddings of rows [row0, row0+rows) into d_out [rows x ceil4(dims)] (validation) */
+int leann_recompute_encode_device(const leann_recompute *r, uint64_t row0, uint64_t rows, float *d_out,
+                                  void *stream);
+size_t leann_recompute_len(const leann_recompute *r);
+void leann_recompute_close(leann_recompute *r);
+/* synthetic encoder inputs (bf16), the recompute twin of leann_synth_rows_device */
+int leann_synth_features_device(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma,
+                                uint32_t stream_id, uint64_t i0, uint64_t n, uint16_t *d_out, void *stream);
+int leann_synth_weights_device(uint64_t seed, uint32_t h, uint32_t dims, uint16_t *d_out, void *stream);
+
 /* G-way merge of per-shard top-k lists gathered by RCCL: inputs
  * [n_shards x nq x k_in], ascending (dist, key) per list (descending = 1 for recompute scores);
  * outputs [nq x k_out]. */

@@ -56,6 +56,14 @@ SIGNATURES = {
                                          C.c_float, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),
     "leann_scan_topk_device": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                         vp, C.c_uint64, vp, vp, vp, vp]),
+    "leann_recompute_create": (C.c_int, [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "leann_recompute_search_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp]),
+    "leann_recompute_encode_device": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
+    "leann_recompute_len": (C.c_size_t, [vp]),
+    "leann_recompute_close": (None, [vp]),
+    "leann_synth_features_device": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64,
+                                             C.c_uint64, vp, vp]),
+    "leann_synth_weights_device": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]),
     "leann_merge_topk_device": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                          C.c_int, vp, vp, vp, vp]),
     "leann_device_count": (C.c_int, [C.POINTER(C.c_int)]),

@@ -1,0 +1,344 @@
+// recompute.hip — the LEANN "no stored vectors" search: embeddings are recomputed on the fly from a
+// device-resident encoder and never kept.
+//
+// Reference path (src/index/recompute.rs:52-123): for every passage, embedding_provider.embed(..)
+// (:86-93) -> dot with the query (:96-103) -> stable sort descending (:106) -> take(k) (:109-120).
+// The provider's last stage is a dense layer + L2 normalisation (candle.rs:165, :218-225:
+// x / max(sqrt(sum x^2), 1e-12)); the transformer in front of it is out of scope (no weights offline),
+// so the device-resident "embedding provider" here is:
+//     per-passage compact feature  f_i  [h]      bf16   (h = 256: 512 B instead of 3 072 B per passage)
+//     encoder weights              W    [h x d]  bf16
+//     embedding_i = l2_normalize(W^T f_i)  with f32 accumulation
+//
+// Per chunk of passages:
+//   encode_normalize_kernel  E = normalise(F W) on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16),
+//                            128 passages x all d columns per workgroup so that the row norm is a
+//                            local reduction (fused epilogue), E written once as f32;
+//   score_mfma_kernel + top-k (scan.hip) over the chunk, candidates carried across chunks.
+// E lives only in a chunk-sized scratch buffer (never N x d).
+#include "common.cuh"
+#include "../../include/leann_backend.h"
+#include <algorithm>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    memcpy(&u, &f, 4);
+#endif
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40); // NaN stays NaN
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// ---- synthetic features / weights: the recompute twin of gen.hip -----------------------------------
+// f_i[k] = bf16(centre_c[k] + sigma * noise_i[k]),  W[k][j] = bf16(gauss(k, j))  (same hash streams as
+// gen.hip with r = h), so normalise(W^T f_i) is the clustered synthetic corpus at bf16 input precision.
+#define TAG_P 0x50524F4A00000000ull
+#define TAG_C 0x43454E5400000000ull
+#define TAG_A 0x4153534700000000ull
+#define TAG_N 0x4E4F495300000000ull
+__global__ void synth_features_kernel(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma, uint32_t stream_id,
+                                      uint64_t i0, uint64_t n, uint16_t *__restrict__ out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * h) return;
+    const uint64_t ii = idx / h, i = i0 + ii;
+    const uint32_t k = (uint32_t)(idx % h);
+    const uint64_t nseed = seed ^ TAG_N ^ ((uint64_t)stream_id * 0x9E3779B97F4A7C15ull);
+    const uint64_t c = hash3(seed ^ TAG_A, stream_id, i) % n_clusters;
+    out[idx] = f32_to_bf16_rne(fmaf(sigma, gauss_ih4(nseed, i, k), gauss_ih4(seed ^ TAG_C, c, k)));
+}
+__global__ void synth_weights_kernel(uint64_t seed, uint32_t h, uint32_t d, uint16_t *__restrict__ W /* [h x d] */) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= h * d) return;
+    W[idx] = f32_to_bf16_rne(gauss_ih4(seed ^ TAG_P, idx / d, idx % d));
+}
+extern "C" int leann_synth_features_device(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma, uint32_t stream_id,
+                                           uint64_t i0, uint64_t n, uint16_t *d_out, void *stream) {
+    if (!d_out || h == 0 || n_clusters == 0) { leann_set_error("leann_synth_features_device: invalid arguments"); return LEANN_ERR_INVALID; }
+    if (n == 0) return LEANN_OK;
+    const uint64_t total = n * h;
+    hipLaunchKernelGGL(synth_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, h,
+                       n_clusters, sigma, stream_id, i0, n, d_out);
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
+}
+extern "C" int leann_synth_weights_device(uint64_t seed, uint32_t h, uint32_t dims, uint16_t *d_out, void *stream) {
+    if (!d_out || h == 0 || dims == 0) { leann_set_error("leann_synth_weights_device: invalid arguments"); return LEANN_ERR_INVALID; }
+    hipLaunchKernelGGL(synth_weights_kernel, dim3((h * dims + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, h, dims, d_out);
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
+}
+
+// ---- weights re-tiled for the MFMA B operand: Wp[kstep][col][16] bf16, col padded to CT*32 ------------
+__global__ void tile_weights_kernel(const uint16_t *__restrict__ W, uint32_t h, uint32_t d, uint32_t hp, uint32_t dp,
+                                    uint16_t *__restrict__ Wp) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= hp * dp) return;
+    const uint32_t ks = idx / (dp * 16), rem = idx % (dp * 16), col = rem / 16, kk = rem % 16, k = ks * 16 + kk;
+    Wp[idx] = (k < h && col < d) ? W[(size_t)k * d + col] : (uint16_t)0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode_normalize_kernel<CT>: 512 threads = 8 waves; workgroup tile = 128 passages x (CT*4*32) columns
+// (CT col tiles of 32 per wave, 4 column groups, 2 row halves of 64 passages).  d <= CT*128.
+// LDS: sF[128][hp + 8] bf16 (whole K, loaded once) + 2 x sW[dp][24] bf16 (one 16-deep k-step each).
+// ------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ void __launch_bounds__(512) encode_normalize_kernel(const uint16_t *__restrict__ F, uint64_t n, uint32_t h,
+                                                               uint32_t hp, const uint16_t *__restrict__ Wp, uint32_t d,
+                                                               uint32_t ld_out, float *__restrict__ E) {
+    constexpr int DP = CT * 128;   // padded columns
+    constexpr int WSTRIDE = 24;    // bf16 per column in a staged k-step (16 + 8 pad: conflict-free b128 reads)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t fstride = hp + 8; // bf16 elements per sF row
+    uint16_t *sF = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *sW = sF + 128 * fstride;                       // [2][DP][WSTRIDE]
+    float *sN = reinterpret_cast<float *>(sW + 2 * DP * WSTRIDE); // [4 col groups][128 rows] partial sum of squares
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int rhalf = wave >> 2, cgrp = wave & 3;
+    const uint64_t row_base = (uint64_t)blockIdx.x * 128;
+
+    // ---- stage the feature tile (zero-padded rows / k) ------------------------------------------------
+    for (uint32_t idx = tid; idx < 128 * (hp / 8); idx += 512) {
+        const uint32_t r = idx / (hp / 8), k8 = (idx % (hp / 8)) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const uint64_t row = row_base + r;
+        if (row < n) {
+            if (k8 + 8 <= h && ((h & 7) == 0)) v = *reinterpret_cast<const uint4 *>(F + row * h + k8);
+            else {
+                uint16_t t[8];
+                for (int e = 0; e < 8; e++) t[e] = (k8 + e < h) ? F[row * h + k8 + e] : (uint16_t)0;
+                memcpy(&v, t, 16);
+            }
+        }
+        *reinterpret_cast<uint4 *>(sF + r * fstride + k8) = v;
+    }
+    auto stage_w = [&](int buf, uint32_t ks) { // 16 k x DP columns, contiguous in Wp
+        const uint4 *src = reinterpret_cast<const uint4 *>(Wp + (size_t)ks * DP * 16);
+        uint16_t *dst = sW + buf * DP * WSTRIDE;
+        for (uint32_t idx = tid; idx < DP * 2; idx += 512) { // 2 x 16 B per column
+            const uint32_t col = idx >> 1, half = idx & 1;
+            *reinterpret_cast<uint4 *>(dst + col * WSTRIDE + half * 8) = src[idx];
+        }
+    };
+    f32x16 acc[2][CT];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[rt][ct][i] = 0.f;
+
+    const uint32_t nks = hp / 16;
+    stage_w(0, 0);
+    __syncthreads();
+    for (uint32_t ks = 0; ks < nks; ks++) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) stage_w(buf ^ 1, ks + 1); // next k-step lands while this one is consumed
+        const uint16_t *w = sW + buf * DP * WSTRIDE;
+        bf16x8 a[2], b[CT];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+            a[rt] = *reinterpret_cast<const bf16x8 *>(sF + (rhalf * 64 + rt * 32 + l31) * fstride + ks * 16 + lh * 8);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+            b[ct] = *reinterpret_cast<const bf16x8 *>(w + ((cgrp * CT + ct) * 32 + l31) * WSTRIDE + lh * 8);
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue: row norms (candle.rs:218-225) then one f32 store of the normalised tile ------
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            float p = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) p = fmaf(acc[rt][ct][reg], acc[rt][ct][reg], p);
+            // sum over the 32 lanes that share lane >> 5 (the 32 columns of a tile)
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            p += __shfl_xor(p, 4, 64);
+            p += __shfl_xor(p, 8, 64);
+            p += __shfl_xor(p, 16, 64);
+            if (l31 == 0) sN[cgrp * 128 + rhalf * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh] = p;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int r = rhalf * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const uint64_t row = row_base + r;
+            const float ss = ((sN[r] + sN[128 + r]) + (sN[256 + r] + sN[384 + r])); // fixed order: reproducible
+            float nrm = sqrtf(ss);
+            nrm = nrm < 1e-12f ? 1e-12f : nrm;
+            if (row < n) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) {
+                    const uint32_t col = (cgrp * CT + ct) * 32 + l31;
+                    if (col < ld_out) E[(size_t)(row - 0) * ld_out + col] = col < d ? acc[rt][ct][reg] / nrm : 0.f;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct leann_recompute {
+    int device = 0;
+    const uint16_t *F = nullptr; // borrowed [n x h]
+    uint16_t *Wp = nullptr;      // owned, tiled
+    size_t n = 0, h = 0, hp = 0, d = 0, dp = 0, ld = 0;
+    uint64_t key_offset = 0;
+    int ct = 0;
+};
+
+static size_t encode_lds_bytes(size_t hp, size_t dp) { return 128 * (hp + 8) * 2 + 2 * dp * 24 * 2 + 4 * 128 * 4; }
+
+static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st) {
+    const size_t lds = encode_lds_bytes(r->hp, r->dp);
+    const unsigned grid = (unsigned)((rows + 127) / 128);
+    const uint16_t *F = r->F + row0 * r->h;
+#define LAUNCH_CT(CT)                                                                                                    \
+    do {                                                                                                                 \
+        HIP_CHECK_RET(hipFuncSetAttribute((const void *)encode_normalize_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          160 * 1024));                                                                  \
+        hipLaunchKernelGGL(encode_normalize_kernel<CT>, dim3(grid), dim3(512), lds, st, F, (uint64_t)rows, (uint32_t)r->h,       \
+                           (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E);                                  \
+    } while (0)
+    switch (r->ct) {
+        case 1: LAUNCH_CT(1); break;
+        case 2: LAUNCH_CT(2); break;
+        case 3: LAUNCH_CT(3); break;
+        case 4: LAUNCH_CT(4); break;
+        case 6: LAUNCH_CT(6); break;
+        default: leann_set_error("recompute: unsupported dims %zu", r->d); return LEANN_ERR_INVALID;
+    }
+#undef LAUNCH_CT
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
+}
+
+extern "C" int leann_recompute_create(const uint16_t *d_features, size_t n, size_t h, const uint16_t *d_weights, size_t dims,
+                                      int device, uint64_t key_offset, leann_recompute **out) {
+    if (!out || (n && !d_features) || !d_weights || h == 0 || dims == 0 || dims > 768 || n >= (1ull << 32)) {
+        leann_set_error("leann_recompute_create: invalid arguments (n=%zu h=%zu dims=%zu; dims <= 768)", n, h, dims);
+        return LEANN_ERR_INVALID;
+    }
+    int ndev = 0;
+    leann_device_count(&ndev);
+    if (device < 0 || device >= ndev) {
+        leann_set_error("HIP device %d not available (%d visible). This library has no CPU fallback.", device, ndev);
+        return LEANN_ERR_DEVICE;
+    }
+    HIP_CHECK_RET(hipSetDevice(device));
+    leann_recompute *r = new leann_recompute();
+    r->device = device;
+    r->F = d_features;
+    r->n = n;
+    r->h = h;
+    r->hp = (h + 15) / 16 * 16;
+    r->d = dims;
+    r->ld = (dims + 3) & ~(size_t)3;
+    int ct = (int)((dims + 127) / 128);
+    if (ct == 5) ct = 6;
+    r->ct = ct;
+    r->dp = (size_t)ct * 128;
+    r->key_offset = key_offset;
+    if (encode_lds_bytes(r->hp, r->dp) > 160 * 1024) {
+        delete r;
+        leann_set_error("recompute: feature width %zu x dims %zu exceeds the 160 KiB LDS tile", h, dims);
+        return LEANN_ERR_INVALID;
+    }
+    HIP_CHECK_RET(hipMalloc((void **)&r->Wp, r->hp * r->dp * 2));
+    const uint32_t total = (uint32_t)(r->hp * r->dp);
+    hipLaunchKernelGGL(tile_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, nullptr, d_weights, (uint32_t)h, (uint32_t)dims,
+                       (uint32_t)r->hp, (uint32_t)r->dp, r->Wp);
+    HIP_CHECK_RET(hipGetLastError());
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    *out = r;
+    return LEANN_OK;
+}
+extern "C" void leann_recompute_close(leann_recompute *r) {
+    if (!r) return;
+    (void)hipFree(r->Wp);
+    delete r;
+}
+extern "C" size_t leann_recompute_len(const leann_recompute *r) { return r ? r->n : 0; }
+
+// materialise the embeddings of rows [row0, row0 + rows) into d_out [rows x ld] (tests / validation)
+extern "C" int leann_recompute_encode_device(const leann_recompute *r, uint64_t row0, uint64_t rows, float *d_out, void *stream) {
+    if (!r || !d_out || row0 + rows > r->n) { leann_set_error("leann_recompute_encode_device: invalid arguments"); return LEANN_ERR_INVALID; }
+    if (rows == 0) return LEANN_OK;
+    HIP_CHECK_RET(hipSetDevice(r->device));
+    return launch_encode(r, row0, rows, d_out, (hipStream_t)stream);
+}
+
+// scan.hip internals reused per chunk
+int leann_internal_scan_chunk(const float *E, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, uint32_t k,
+                              const uint8_t *allow, uint64_t row0, float *S, uint64_t *cand, size_t cand_len, size_t seg_off,
+                              hipStream_t st, size_t *segs_out);
+int leann_internal_scan_finish(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k,
+                               uint64_t key_offset, uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st);
+
+// RecomputeSearcher::search arithmetic for a batch of queries — recompute.rs:86-109 on the GPU.
+extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, const float *d_queries, size_t nq, size_t top_k,
+                                                   const uint8_t *d_allow_mask, uint64_t *d_keys, float *d_scores,
+                                                   uint32_t *d_counts, void *stream) {
+    if (!r || !d_queries || !d_keys || !d_scores || !d_counts || top_k == 0 || top_k > 1024) {
+        leann_set_error("leann_recompute_search_batch_device: invalid arguments");
+        return LEANN_ERR_INVALID;
+    }
+    if (nq == 0) return LEANN_OK;
+    HIP_CHECK_RET(hipSetDevice(r->device));
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t k = (uint32_t)top_k;
+    const size_t SEGSZ = 2048;
+    // chunk so that E (rows x ld f32) <= ~3 GiB and the score slab (nq x rows f32) <= 2 GiB
+    size_t chunk = std::min<size_t>(((size_t)3 << 30) / (r->ld * 4), ((size_t)1 << 29) / std::max<size_t>(nq, 1));
+    chunk = std::max<size_t>(SEGSZ, chunk / SEGSZ * SEGSZ);
+    chunk = std::min(chunk, (std::max<size_t>(r->n, 1) + SEGSZ - 1) / SEGSZ * SEGSZ);
+    const size_t n_chunks = r->n ? (r->n + chunk - 1) / chunk : 0;
+    size_t total_segs = 0;
+    for (size_t c = 0; c < n_chunks; c++) total_segs += (std::min(chunk, r->n - c * chunk) + SEGSZ - 1) / SEGSZ;
+    total_segs = std::max<size_t>(total_segs, 1);
+    const size_t cand_len = std::max<size_t>(total_segs * k, k);
+    float *E = nullptr, *S = nullptr;
+    uint64_t *candA = nullptr, *candB = nullptr;
+    HIP_CHECK_RET(hipMalloc((void **)&E, chunk * r->ld * 4));
+    HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * nq * chunk));
+    HIP_CHECK_RET(hipMalloc((void **)&candA, sizeof(uint64_t) * nq * cand_len));
+    HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
+    HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
+    size_t seg_off = 0;
+    int rc = LEANN_OK;
+    for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
+        const size_t row0 = c * chunk, rows = std::min(chunk, r->n - row0);
+        rc = launch_encode(r, row0, rows, E, st);
+        size_t segs = 0;
+        if (rc == LEANN_OK)
+            rc = leann_internal_scan_chunk(E, rows, r->d, r->ld, d_queries, nq, k, d_allow_mask, row0, S, candA, cand_len, seg_off, st, &segs);
+        seg_off += segs;
+    }
+    if (rc == LEANN_OK)
+        rc = leann_internal_scan_finish(candA, candB, cand_len, total_segs, nq, k, r->key_offset, d_keys, d_scores, d_counts, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(E);
+    (void)hipFree(S);
+    (void)hipFree(candA);
+    (void)hipFree(candB);
+    return rc;
+}

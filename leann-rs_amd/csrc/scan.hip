@@ -6,9 +6,9 @@
 // SURVEY.md), ties keep the lower position (Rust sort_by is stable, N4).
 //
 // Kernels:
-//   score_tile_kernel   S[q][i] = sum_j x_i[j]*q[j] as ONE k-ordered fmaf chain per (q, i)
-//                       (oracle: orc_dot_seqfma; |.-orc_dot_seq| <= 1e-5 is tested) — LDS-tiled,
-//                       128 rows x 64 queries per workgroup, 8x4 register tile per thread.
+//   score_mfma_kernel   S[q][i] = sum_j x_i[j]*q[j] as ONE k-ordered fmaf chain per (q, i)
+//                       (oracle: orc_dot_seqfma; |.-orc_dot_seq| <= 1e-5 is tested) — f32 MFMA
+//                       (v_mfma_f32_32x32x2_f32), 128 rows x 64 queries per workgroup from LDS tiles.
 //   topk_scores_kernel  per (query, segment of SEG scores): bitonic sort of u64 keys
 //                       (~orderable(score) << 32 | position) in LDS, emit the k smallest.
 //   topk_keys_kernel    same on lists of keys (reduction rounds).
@@ -20,59 +20,78 @@
 #define SEG 2048
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) score_tile_kernel(const float *__restrict__ X, uint64_t n, uint32_t d,
+// score_mfma_kernel: S[q][i] for a tile of 128 rows x 64 queries on the f32 matrix cores.
+// v_mfma_f32_32x32x2_f32 computes D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) — a k-ordered f32 fmaf
+// chain, bit for bit (MI355X_MICROARCH.md §Matrix cores), so every score is the same single chain
+// acc = fmaf(x[j], q[j], acc), j ascending, that oracle/oracle.c:orc_dot_seqfma evaluates.
+// A operand = queries (i = query), B operand = rows (j = row): the 32 lanes of a half-wave then
+// hold 32 consecutive rows of one query -> 128-B coalesced stores into S[q][row].
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__global__ void __launch_bounds__(256) score_mfma_kernel(const float *__restrict__ X, uint64_t n, uint32_t d,
                                                          uint32_t ld, const float *__restrict__ Q, uint32_t nq,
                                                          uint32_t ldq, uint64_t row0, uint32_t n_rows,
                                                          float *__restrict__ S /* [nq x n_rows] */) {
-    constexpr int BR = 128, BQ = 64, BK = 16;
-    __shared__ float sA[BK][BR + 4];
-    __shared__ float sB[BK][BQ + 4];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4; // ty: 16 row groups of 8, tx: 16 query groups of 4
+    constexpr int BR = 128, BQ = 64, BK = 32;
+    __shared__ float sX[BK][BR + 4]; // [k][row]
+    __shared__ float sQ[BK][BQ + 4]; // [k][query]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
     const uint32_t rbase = blockIdx.x * BR, qbase = blockIdx.y * BQ;
-    float acc[8][4];
+    f32x16 acc0, acc1; // query tile 0 / 1  x  row tile `wave`
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
+    for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     for (uint32_t k0 = 0; k0 < d; k0 += BK) {
-        // stage A: 128 rows x 16 k  (each thread 8 floats), B: 64 queries x 16 k (4 floats)
-        {
-            int r = tid >> 1, kk = (tid & 1) * 8;
-            uint32_t row = rbase + r;
+        { // stage rows: thread -> (row = tid/2, 16 consecutive k)
+            const int r = tid >> 1, kk = (tid & 1) * 16;
+            const uint32_t row = rbase + r;
             const float *src = X + (size_t)(row0 + row) * ld + k0 + kk;
+            const bool rok = row < n_rows;
 #pragma unroll
-            for (int e = 0; e < 8; e++)
-                sA[kk + e][r] = (row < n_rows && k0 + kk + e < d) ? src[e] : 0.f;
-            int qq = tid >> 2, kq = (tid & 3) * 4;
-            uint32_t qi = qbase + qq;
-            const float *qs = Q + (size_t)qi * ldq + k0 + kq;
+            for (int e4 = 0; e4 < 4; e4++) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                const uint32_t kq = k0 + kk + e4 * 4;
+                if (rok) {
+                    if (vec_ok && kq + 3 < ld) {
+                        float4 t = *reinterpret_cast<const float4 *>(src + e4 * 4);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                sB[kq + e][qq] = (qi < nq && k0 + kq + e < d) ? qs[e] : 0.f;
+                        for (int e = 0; e < 4; e++) if (kq + e < ld) v[e] = src[e4 * 4 + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) sX[kk + e4 * 4 + e][r] = (kq + e < d) ? v[e] : 0.f;
+            }
+            // stage queries: thread -> (query = tid/4, 8 consecutive k)
+            const int qq = tid >> 2, kq0 = (tid & 3) * 8;
+            const uint32_t qi = qbase + qq;
+            const float *qs = Q + (size_t)qi * ldq + k0 + kq0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) sQ[kq0 + e][qq] = (qi < nq && k0 + kq0 + e < d) ? qs[e] : 0.f;
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < BK; kk++) {
-            float a[8], b[4];
-#pragma unroll
-            for (int i = 0; i < 8; i++) a[i] = sA[kk][ty * 8 + i];
-#pragma unroll
-            for (int j = 0; j < 4; j++) b[j] = sB[kk][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int s = 0; s < BK / 2; s++) {
+            const float b = sX[2 * s + lh][wave * 32 + l31];
+            const float a0 = sQ[2 * s + lh][l31];
+            const float a1 = sQ[2 * s + lh][32 + l31];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
         }
         __syncthreads();
     }
+    // C/D layout: col = lane & 31 (row of X), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
+    const uint32_t row = rbase + wave * 32 + l31;
+    if (row < n_rows) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        uint32_t qi = qbase + tx * 4 + j;
-        if (qi >= nq) continue;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint32_t row = rbase + ty * 8 + i;
-            if (row < n_rows) S[(size_t)qi * n_rows + row] = acc[i][j];
+        for (int reg = 0; reg < 16; reg++) {
+            const uint32_t qoff = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const uint32_t q0 = qbase + qoff, q1 = qbase + 32 + qoff;
+            if (q0 < nq) S[(size_t)q0 * n_rows + row] = acc0[reg];
+            if (q1 < nq) S[(size_t)q1 * n_rows + row] = acc1[reg];
         }
     }
 }
@@ -157,6 +176,38 @@ __global__ void finalize_scan_kernel(const uint64_t *__restrict__ keys, uint32_t
     }
 }
 
+// one chunk: scores of rows [0, rows) of Xbase against all queries, per-segment top-k appended to cand
+int leann_internal_scan_chunk(const float *Xbase, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, uint32_t k,
+                              const uint8_t *allow, uint64_t pos0, float *S, uint64_t *cand, size_t cand_len, size_t seg_off,
+                              hipStream_t st, size_t *segs_out) {
+    dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
+    hipLaunchKernelGGL(score_mfma_kernel, g1, dim3(256), 0, st, Xbase, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld, d_queries,
+                       (uint32_t)nq, (uint32_t)dims, (uint64_t)0, (uint32_t)rows, S);
+    unsigned segs = (unsigned)((rows + SEG - 1) / SEG);
+    hipLaunchKernelGGL(topk_scores_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, S, (uint32_t)rows, pos0, allow, k, cand,
+                       (uint32_t)cand_len, (uint32_t)seg_off);
+    HIP_CHECK_RET(hipGetLastError());
+    *segs_out = segs;
+    return LEANN_OK;
+}
+// reduction rounds until one segment per query remains, then keys -> (position + key_offset, score)
+int leann_internal_scan_finish(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k,
+                               uint64_t key_offset, uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st) {
+    size_t m = total_segs * k;
+    uint64_t *src = candA, *dst = candB;
+    while (m > k) {
+        unsigned segs = (unsigned)((m + SEG - 1) / SEG);
+        hipLaunchKernelGGL(topk_keys_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, src, (uint32_t)m, (uint32_t)cand_len, k, dst,
+                           (uint32_t)cand_len);
+        m = (size_t)segs * k;
+        std::swap(src, dst);
+    }
+    hipLaunchKernelGGL(finalize_scan_kernel, dim3((unsigned)nq), dim3(64), 0, st, src, (uint32_t)cand_len, (uint32_t)nq, k, key_offset,
+                       d_keys, d_scores, d_counts);
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
+}
+
 extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims, size_t ld, const float *d_queries,
                                       size_t nq, size_t top_k, const uint8_t *d_allow_mask, uint64_t key_offset,
                                       uint64_t *d_keys, float *d_scores, uint32_t *d_counts, void *stream) {
@@ -173,10 +224,7 @@ extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims
     chunk = (chunk + SEG - 1) / SEG * SEG;
     size_t n_chunks = n ? (n + chunk - 1) / chunk : 0;
     size_t total_segs = 0;
-    for (size_t c = 0; c < n_chunks; c++) {
-        size_t rows = std::min(chunk, n - c * chunk);
-        total_segs += (rows + SEG - 1) / SEG;
-    }
+    for (size_t c = 0; c < n_chunks; c++) total_segs += (std::min(chunk, n - c * chunk) + SEG - 1) / SEG;
     if (total_segs == 0) total_segs = 1;
     float *S = nullptr;
     uint64_t *candA = nullptr, *candB = nullptr;
@@ -186,38 +234,22 @@ extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims
     HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
     HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
     size_t seg_off = 0;
-    for (size_t c = 0; c < n_chunks; c++) {
-        size_t row0 = c * chunk, rows = std::min(chunk, n - row0);
-        dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
-        hipLaunchKernelGGL(score_tile_kernel, g1, dim3(256), 0, st, d_rows, (uint64_t)n, (uint32_t)dims, (uint32_t)ld,
-                           d_queries, (uint32_t)nq, (uint32_t)dims, (uint64_t)row0, (uint32_t)rows, S);
-        unsigned segs = (unsigned)((rows + SEG - 1) / SEG);
-        hipLaunchKernelGGL(topk_scores_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, S, (uint32_t)rows,
-                           (uint64_t)row0, d_allow_mask, k, candA, (uint32_t)cand_len, (uint32_t)seg_off);
+    int rc = LEANN_OK;
+    for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
+        size_t row0 = c * chunk, rows = std::min(chunk, n - row0), segs = 0;
+        rc = leann_internal_scan_chunk(d_rows + row0 * ld, rows, dims, ld, d_queries, nq, k, d_allow_mask, row0, S, candA, cand_len,
+                                       seg_off, st, &segs);
         seg_off += segs;
     }
-    HIP_CHECK_RET(hipGetLastError());
-    // reduction rounds until one segment per query remains
-    size_t m = total_segs * k;
-    uint64_t *src = candA, *dst = candB;
-    while (m > k) {
-        unsigned segs = (unsigned)((m + SEG - 1) / SEG);
-        hipLaunchKernelGGL(topk_keys_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, src, (uint32_t)m,
-                           (uint32_t)cand_len, k, dst, (uint32_t)cand_len);
-        m = (size_t)segs * k;
-        std::swap(src, dst);
-        if (segs == 1) break;
-    }
-    hipLaunchKernelGGL(finalize_scan_kernel, dim3((unsigned)nq), dim3(64), 0, st, src, (uint32_t)cand_len, (uint32_t)nq,
-                       k, key_offset, d_keys, d_scores, d_counts);
-    HIP_CHECK_RET(hipGetLastError());
+    if (rc == LEANN_OK)
+        rc = leann_internal_scan_finish(candA, candB, cand_len, total_segs, nq, k, key_offset, d_keys, d_scores, d_counts, st);
     // scratch is plain hipMalloc memory: wait for the stream before giving it back (this entry point
     // is synchronous; the stream-ordered allocator proved unreliable on this stack)
-    HIP_CHECK_RET(hipStreamSynchronize(st));
-    HIP_CHECK_RET(hipFree(S));
-    HIP_CHECK_RET(hipFree(candA));
-    HIP_CHECK_RET(hipFree(candB));
-    return LEANN_OK;
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(S);
+    (void)hipFree(candA);
+    (void)hipFree(candB);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

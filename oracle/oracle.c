@@ -223,6 +223,50 @@ void orc_l2_normalize(float *x, uint32_t d) { /* candle.rs:218-225 */
 }
 
 /* ============================================================================================
+ * Recompute "embedding provider" restatement: dense layer + L2 normalise — the tail of
+ * src/embedding/candle.rs:165 (forward), :218-225 (l2_normalize), with bf16 inputs and f32
+ * accumulation (csrc/recompute.hip).  GPU accumulates on MFMA in a different order: parity for this
+ * floating-point stage is tolerance based (1e-5 on scores, tests/test_gpu_recompute.py).
+ * ========================================================================================== */
+uint16_t orc_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+void orc_synth_features(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma, uint32_t stream,
+                        uint64_t i0, uint64_t n, uint16_t *out) {
+    uint64_t nseed = seed ^ TAG_N ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ull);
+    for (uint64_t ii = 0; ii < n; ii++) {
+        uint64_t i = i0 + ii, c = orc_hash3(seed ^ TAG_A, stream, i) % n_clusters;
+        for (uint32_t k = 0; k < h; k++)
+            out[ii * h + k] = orc_bf16_rne(fmaf(sigma, orc_gauss(nseed, i, k), orc_gauss(seed ^ TAG_C, c, k)));
+    }
+}
+void orc_synth_weights(uint64_t seed, uint32_t h, uint32_t d, uint16_t *out) {
+    for (uint32_t k = 0; k < h; k++)
+        for (uint32_t j = 0; j < d; j++) out[(size_t)k * d + j] = orc_bf16_rne(orc_gauss(seed ^ TAG_P, k, j));
+}
+void orc_recompute_encode(const uint16_t *F, uint64_t n, uint32_t h, const uint16_t *W, uint32_t d, float *out) {
+    for (uint64_t i = 0; i < n; i++) {
+        float *x = out + i * d;
+        for (uint32_t j = 0; j < d; j++) x[j] = 0.0f;
+        for (uint32_t k = 0; k < h; k++) {
+            float fk = bf16_f32(F[i * h + k]);
+            const uint16_t *wk = W + (size_t)k * d;
+            for (uint32_t j = 0; j < d; j++) x[j] = fmaf(bf16_f32(wk[j]), fk, x[j]);
+        }
+        orc_l2_normalize(x, d);
+    }
+}
+
+/* ============================================================================================
  * Graph index
  * ========================================================================================== */
 struct orc_graph {

@@ -102,6 +102,13 @@ void orc_merge_topk(const uint64_t *keys, const float *dists, const uint32_t *co
 void orc_hybrid_rerank(const uint64_t *idx, const float *vscore, uint32_t n, const float *bm25,
                        uint64_t n_bm25, float alpha, uint64_t *out_idx, float *out_score);
 
+/* ---- recompute encoder restatement (dense + L2 normalise, bf16 inputs, f32 accumulate) ---------- */
+uint16_t orc_bf16_rne(float f);
+void orc_synth_features(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma, uint32_t stream,
+                        uint64_t i0, uint64_t n, uint16_t *out);
+void orc_synth_weights(uint64_t seed, uint32_t h, uint32_t d, uint16_t *out);
+void orc_recompute_encode(const uint16_t *F, uint64_t n, uint32_t h, const uint16_t *W, uint32_t d, float *out);
+
 /* ---- pooling / normalise glue (src/embedding/candle.rs:191-225) ---------------------------- */
 void orc_l2_normalize(float *x, uint32_t d); /* x / max(sqrt(sum x^2), 1e-12), sequential sum */
 

@@ -68,6 +68,11 @@ def lib():
         L.orc_hybrid_rerank.argtypes = [u64p, f32p, C.c_uint32, f32p, C.c_uint64, C.c_float, u64p,
                                         f32p]
         L.orc_l2_normalize.argtypes = [f32p, C.c_uint32]
+        u16p = C.POINTER(C.c_uint16)
+        L.orc_synth_features.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64,
+                                         C.c_uint64, u16p]
+        L.orc_synth_weights.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, u16p]
+        L.orc_recompute_encode.argtypes = [u16p, C.c_uint64, C.c_uint32, u16p, C.c_uint32, f32p]
         _LIB = L
     return _LIB
 
@@ -176,6 +181,28 @@ class Graph:
             lib().orc_graph_free(self.h)
         except Exception:
             pass
+
+
+def synth_features(seed, h, n_clusters, sigma, stream, i0, n):
+    out = np.empty((n, h), np.uint16)
+    lib().orc_synth_features(seed, h, n_clusters, sigma, stream, i0, n, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def synth_weights(seed, h, d):
+    out = np.empty((h, d), np.uint16)
+    lib().orc_synth_weights(seed, h, d, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def recompute_encode(F, W):
+    F = np.ascontiguousarray(F, np.uint16)
+    W = np.ascontiguousarray(W, np.uint16)
+    out = np.empty((F.shape[0], W.shape[1]), np.float32)
+    u16p = C.POINTER(C.c_uint16)
+    lib().orc_recompute_encode(F.ctypes.data_as(u16p), F.shape[0], F.shape[1], W.ctypes.data_as(u16p), W.shape[1],
+                               _p(out, f32p))
+    return out
 
 
 def merge_topk(keys, dists, counts, k_out):

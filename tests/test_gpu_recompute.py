@@ -1,0 +1,85 @@
+"""-m gpu: recompute search (no stored vectors) — bf16-MFMA encode + normalise, f32-MFMA scoring, top-k —
+against the oracle restatement of src/index/recompute.rs:86-109 with the dense + L2-normalise provider
+tail (src/embedding/candle.rs:165,218-225).  Floating-point stage: tolerance 1e-5 on embeddings and
+scores (north_star: "cosine scores within 1e-5"); ids must agree wherever score gaps exceed 2e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED0001
+
+
+def _mk(la, po, n, h, d, nq):
+    L, chk = la.lib(), la._native.check
+    F = po.synth_features(SEED, h, 64, 1.0, 0, 0, n)
+    W = po.synth_weights(SEED, h, d)
+    Fq = po.synth_features(SEED, h, 64, 1.0, 1, 0, nq)
+    Q = po.recompute_encode(Fq, W)  # queries = embeddings of query-side features
+    dF, dW = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W)
+    # device generators are bit-identical to the oracle's
+    gF, gW = la.DeviceArray((n, h), np.uint16), la.DeviceArray((h, d), np.uint16)
+    chk(L.leann_synth_features_device(SEED, h, 64, 1.0, 0, 0, n, gF.ptr, None))
+    chk(L.leann_synth_weights_device(SEED, h, d, gW.ptr, None))
+    la.sync()
+    assert (gF.to_host() == F).all() and (gW.to_host() == W).all()
+    r = C.c_void_p()
+    chk(L.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))
+    return L, chk, F, W, Q, r, (dF, dW)
+
+
+@pytest.mark.parametrize("n,h,d", [(3000, 256, 768), (1000, 64, 128), (777, 100, 200), (5000, 256, 384)])
+def test_encode_matches_oracle(la, po, gpu, n, h, d):
+    L, chk, F, W, Q, r, keep = _mk(la, po, n, h, d, 4)
+    ld = (d + 3) // 4 * 4
+    dE = la.DeviceArray((n, ld), np.float32)
+    chk(L.leann_recompute_encode_device(r, 0, n, dE.ptr, None))
+    la.sync()
+    E = dE.to_host()[:, :d]
+    ref = po.recompute_encode(F, W)
+    assert np.abs(E - ref).max() <= 1e-6
+    assert np.abs(np.linalg.norm(E, axis=1) - 1).max() <= 1e-5
+    L.leann_recompute_close(r)
+
+
+@pytest.mark.parametrize("n,h,d,nq,k", [(6000, 256, 768, 70, 10), (2500, 64, 128, 5, 3), (4100, 128, 256, 64, 16)])
+def test_recompute_search_matches_restatement(la, po, gpu, n, h, d, nq, k):
+    L, chk, F, W, Q, r, keep = _mk(la, po, n, h, d, nq)
+    dQ = la.DeviceArray.from_host(Q)
+    dk, ds, dc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    chk(L.leann_recompute_search_batch_device(r, dQ.ptr, nq, k, None, dk.ptr, ds.ptr, dc.ptr, None))
+    la.sync()
+    gk, gs, gc = dk.to_host(), ds.to_host(), dc.to_host()
+    assert (gc == k).all()
+    E = po.recompute_encode(F, W)  # the reference materialises every embedding (recompute.rs:86-93) ...
+    for i in range(nq):
+        k0, s0 = po.scan_topk(E, Q[i], k + 5, mode=0)  # ... then dot_product + stable sort desc + take (:96-109)
+        assert np.abs(gs[i] - s0[:k]).max() <= 1e-5
+        assert (np.diff(gs[i]) <= 0).all()
+        for j in range(k):
+            if gk[i, j] != k0[j]:  # only allowed across a near-tie
+                assert abs(s0[j] - s0[list(k0).index(gk[i, j])]) <= 2e-5 if gk[i, j] in k0 else False
+    L.leann_recompute_close(r)
+
+
+def test_recompute_allow_mask_and_offset(la, po, gpu):
+    n, h, d, nq, k = 3000, 64, 128, 6, 8
+    L, chk, F, W, Q, r0, keep = _mk(la, po, n, h, d, nq)
+    L.leann_recompute_close(r0)
+    r = C.c_void_p()
+    chk(L.leann_recompute_create(keep[0].ptr, n, h, keep[1].ptr, d, 0, 1000000, C.byref(r)))  # key_offset
+    mask = np.zeros((n + 7) // 8, np.uint8)
+    for i in range(0, n, 3):
+        mask[i >> 3] |= 1 << (i & 7)
+    dM, dQ = la.DeviceArray.from_host(mask), la.DeviceArray.from_host(Q)
+    dk, ds, dc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    chk(L.leann_recompute_search_batch_device(r, dQ.ptr, nq, k, dM.ptr, dk.ptr, ds.ptr, dc.ptr, None))
+    la.sync()
+    gk = dk.to_host()
+    assert (gk >= 1000000).all() and ((gk - 1000000) % 3 == 0).all()
+    E = po.recompute_encode(F, W)
+    for i in range(nq):
+        k0, s0 = po.scan_topk(E, Q[i], k, mode=0, allow_mask=mask)
+        assert np.abs(ds.to_host()[i] - s0).max() <= 1e-5
+    L.leann_recompute_close(r)
