@@ -37,7 +37,13 @@ WORKLOADS = {
     "hnsw1m": dict(rows=1_000_000, d=768, M=32, efc=128, ef=128),     # BASELINE configs[1]
     "hnsw100k": dict(rows=100_000, d=768, M=32, efc=128, ef=128),     # quick check
     "vamana10m1536": dict(rows=10_000_000, d=1536, M=32, efc=128, ef=128, backend=1),  # configs[4] search leg
+    "vamana1m1536": dict(rows=1_000_000, d=1536, M=32, efc=128, ef=128, backend=1),
+    # configs[2]: recompute-on (no stored vectors), batch-64 queries: features [rows x 256] bf16 + W [256 x 768] bf16
+    "recompute10m": dict(rows=10_000_000, d=768, h=256, kind="recompute", batch=64),
+    "recompute1m": dict(rows=1_000_000, d=768, h=256, kind="recompute", batch=64),
 }
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = f32 vector peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
 SEED, GEN_R, GEN_CLUSTERS, GEN_SIGMA = 0x5EED0001, 64, 4096, 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -52,6 +58,101 @@ def host_cores():
     except Exception:
         pass
     return max(1, n)
+
+
+def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log):
+    """configs[2]: brute-force search with on-the-fly embedding recompute (src/index/recompute.rs:52-123).
+    One step = one batch of 64 queries against all `rows` passages: encode GEMM (bf16 MFMA) + scoring
+    GEMM (f32 MFMA) + top-k.  N > 1: passages are partitioned, per-shard top-k all-gathered and merged."""
+    from leann_rs_amd.shard import exchange_topk, _hip_merge as hip_merge
+    rows, d, h = wl["rows"], wl["d"], wl["h"]
+    B = wl["batch"] if args.batch == 16384 else args.batch
+    k = args.k
+    ld = (d + 3) // 4 * 4
+    steps, warmup = min(args.steps, 10), min(args.warmup, 1)
+    shard = world > 1
+    row0 = rank * rows if shard else 0
+    stream = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(stream.cuda_stream)
+    F = torch.empty((rows, h), dtype=torch.int16, device=dev)
+    W = torch.empty((h, d), dtype=torch.int16, device=dev)
+    Fq = torch.empty((B * 4, h), dtype=torch.int16, device=dev)
+    Q = torch.empty((B * 4, ld), dtype=torch.float32, device=dev)
+    chk(L.leann_synth_features_device(SEED, h, GEN_CLUSTERS, GEN_SIGMA, 0, row0, rows, F.data_ptr(), sp))
+    chk(L.leann_synth_weights_device(SEED, h, d, W.data_ptr(), sp))
+    chk(L.leann_synth_features_device(SEED, h, GEN_CLUSTERS, GEN_SIGMA, 1, 0, B * 4, Fq.data_ptr(), sp))
+    stream.synchronize()
+    r, rq = C.c_void_p(), C.c_void_p()
+    chk(L.leann_recompute_create(F.data_ptr(), rows, h, W.data_ptr(), d, local_rank, row0, C.byref(r)))
+    chk(L.leann_recompute_create(Fq.data_ptr(), B * 4, h, W.data_ptr(), d, local_rank, 0, C.byref(rq)))
+    chk(L.leann_recompute_encode_device(rq, 0, B * 4, Q.data_ptr(), sp))  # queries = embeddings of query-side features
+    stream.synchronize()
+    keys = torch.empty((B, k), dtype=torch.int64, device=dev)
+    scores = torch.empty((B, k), dtype=torch.float32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    ms = (C.c_float * 3)()
+    tm = []
+
+    def step(i):
+        qptr = Q.data_ptr() + (i % 4) * B * ld * 4
+        chk(L.leann_recompute_search_batch_device(r, qptr, B, k, None, keys.data_ptr(), scores.data_ptr(), counts.data_ptr(), sp))
+        L.leann_recompute_last_timing(r, ms)
+        tm.append((ms[0], ms[1], ms[2]))
+        if shard:
+            with torch.cuda.stream(stream):
+                gk, gs, gc = exchange_topk(keys, scores, counts, world)
+                return hip_merge(gk, gs, gc, k, True, stream.cuda_stream)[0]
+        return keys
+
+    for w in range(warmup):
+        step(w)
+    stream.synchronize()
+    tm.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        step(s_)
+    stream.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    enc_ms, sc_ms, tk_ms = [float(np.mean([t[i] for t in tm])) for i in range(3)]
+    enc_flops, sc_flops = 2.0 * rows * h * d, 2.0 * rows * d * B
+    enc_tf, sc_tf = enc_flops / (enc_ms * 1e-3) / 1e12, sc_flops / (sc_ms * 1e-3) / 1e12
+    dominant_score = sc_ms >= enc_ms
+    roof = {"bound": "mfma", "unit": "TFLOP/s", "traffic": None,
+            "kernel": "score_mfma_kernel (f32 MFMA 32x32x2)" if dominant_score else "encode_normalize_kernel<6> (bf16 MFMA 32x32x16)",
+            "achieved": sc_tf if dominant_score else enc_tf,
+            "peak": F32_MFMA_PEAK_TFLOPS if dominant_score else BF16_MFMA_PEAK_TFLOPS}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof.update({"encode_ms": enc_ms, "score_ms": sc_ms, "topk_ms": tk_ms,
+                 "encode_tflops_bf16": enc_tf, "encode_frac_of_bf16_peak": enc_tf / BF16_MFMA_PEAK_TFLOPS,
+                 "score_tflops_f32": sc_tf, "score_frac_of_f32_mfma_peak": sc_tf / F32_MFMA_PEAK_TFLOPS,
+                 "algorithmic_flops_per_step": enc_flops + sc_flops,
+                 "algorithmic_bytes_per_step": rows * h * 2 + h * d * 2})
+    out = {"metric": "queries/sec @ recall@10>=0.95", "value": B * steps * world / elapsed, "unit": "queries/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16 encode / f32 score", "data": "synthetic", "recall_at_10": 1.0,
+           "config": {"workload": f"{args.workload}: recompute-on (no stored vectors), {rows} passages x {h} bf16 features per GPU, "
+                                  f"encoder W[{h}x{d}] bf16, embedding = l2norm(W^T f), batch {B} queries/step, exhaustive scan (exact)",
+                      "rows_per_gpu": rows, "dims": d, "feature_dim": h, "batch": B, "top_k": k,
+                      "parallelism": "single" if world == 1 else f"shard{world}+rccl_allgather"},
+           "roofline": roof}
+    if shard:
+        out["end_to_end_qps"] = B * steps / elapsed
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -95,6 +196,8 @@ def main():
             print("[bench]", *a, file=sys.stderr, flush=True)
 
     wl = dict(WORKLOADS[args.workload])
+    if wl.get("kind") == "recompute":
+        return bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log)
     rows, d, M, efc = wl["rows"], wl["d"], wl["M"], wl["efc"]
     ef = args.ef or wl["ef"]
     backend = wl.get("backend", 0)

@@ -155,6 +155,8 @@ int leann_recompute_search_batch_device(const leann_recompute *r, const float *d
 int leann_recompute_encode_device(const leann_recompute *r, uint64_t row0, uint64_t rows, float *d_out,
                                   void *stream);
 size_t leann_recompute_len(const leann_recompute *r);
+/* HIP-event milliseconds of the last search call: [0] encode GEMM, [1] scoring GEMM, [2] top-k */
+int leann_recompute_last_timing(const leann_recompute *r, float *ms3);
 void leann_recompute_close(leann_recompute *r);
 /* synthetic encoder inputs (bf16), the recompute twin of leann_synth_rows_device */
 int leann_synth_features_device(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma,

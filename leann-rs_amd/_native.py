@@ -60,6 +60,7 @@ SIGNATURES = {
     "leann_recompute_search_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp]),
     "leann_recompute_encode_device": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
     "leann_recompute_len": (C.c_size_t, [vp]),
+    "leann_recompute_last_timing": (C.c_int, [vp, f32p]),
     "leann_recompute_close": (None, [vp]),
     "leann_synth_features_device": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64,
                                              C.c_uint64, vp, vp]),

@@ -270,13 +270,22 @@ __global__ void iota_skip_kernel(uint32_t *p, size_t n, uint32_t first) { // [fi
     if (i >= n) return;
     p[i] = i == 0 ? first : (i <= first ? (uint32_t)(i - 1) : (uint32_t)i);
 }
-// column sums for the Vamana medoid (mean direction), one block per 64 columns-chunk... simple version
-__global__ void col_mean_kernel(const float *__restrict__ X, size_t n, uint32_t d, uint32_t ld, float *__restrict__ mean) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+// column means for the Vamana medoid (mean direction): S row-slices x columns partial sums in f64,
+// then a fixed-order reduction over the slices (reproducible).
+__global__ void col_partial_kernel(const float *__restrict__ X, size_t n, uint32_t d, uint32_t ld, uint32_t S,
+                                   double *__restrict__ part /* [S x ld] */) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, sl = blockIdx.y;
     if (j >= ld) return;
-    if (j >= d) { mean[j] = 0.f; return; }
     double s = 0.0;
-    for (size_t i = 0; i < n; i++) s += X[i * ld + j];
+    if (j < d)
+        for (size_t i = sl; i < n; i += S) s += X[i * ld + j];
+    part[(size_t)sl * ld + j] = s;
+}
+__global__ void col_mean_kernel(const double *__restrict__ part, size_t n, uint32_t ld, uint32_t S, float *__restrict__ mean) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    double s = 0.0;
+    for (uint32_t sl = 0; sl < S; sl++) s += part[(size_t)sl * ld + j];
     mean[j] = (float)(s / (double)n);
 }
 
@@ -462,7 +471,13 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
             float *mean = nullptr; uint64_t *mk = nullptr; float *ms = nullptr; uint32_t *mc = nullptr;
             BCHECK(hipMalloc((void **)&mean, h->g.ld * 4));
             BCHECK(hipMalloc((void **)&mk, 8)); BCHECK(hipMalloc((void **)&ms, 4)); BCHECK(hipMalloc((void **)&mc, 4));
-            hipLaunchKernelGGL(col_mean_kernel, dim3((h->g.ld + 63) / 64), dim3(64), 0, b.st, h->g.X, n, h->g.d, h->g.ld, mean);
+            const uint32_t S = 1024;
+            double *part = nullptr;
+            BCHECK(hipMalloc((void **)&part, (size_t)S * h->g.ld * 8));
+            hipLaunchKernelGGL(col_partial_kernel, dim3((h->g.ld + 63) / 64, S), dim3(64), 0, b.st, h->g.X, n, h->g.d, h->g.ld, S, part);
+            hipLaunchKernelGGL(col_mean_kernel, dim3((h->g.ld + 63) / 64), dim3(64), 0, b.st, part, n, h->g.ld, S, mean);
+            BCHECK(hipStreamSynchronize(b.st));
+            (void)hipFree(part);
             rc = leann_scan_topk_device(h->g.X, n, h->g.d, h->g.ld, mean, 1, 1, nullptr, 0, mk, ms, mc, b.st);
             if (rc) return rc;
             uint64_t key = 0;

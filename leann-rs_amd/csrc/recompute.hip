@@ -204,6 +204,7 @@ struct leann_recompute {
     size_t n = 0, h = 0, hp = 0, d = 0, dp = 0, ld = 0;
     uint64_t key_offset = 0;
     int ct = 0;
+    float last_ms[3] = {0, 0, 0}; // encode, score, top-k of the last search call (HIP events)
 };
 
 static size_t encode_lds_bytes(size_t hp, size_t dp) { return 128 * (hp + 8) * 2 + 2 * dp * 24 * 2 + 4 * 128 * 4; }
@@ -278,6 +279,11 @@ extern "C" void leann_recompute_close(leann_recompute *r) {
     delete r;
 }
 extern "C" size_t leann_recompute_len(const leann_recompute *r) { return r ? r->n : 0; }
+extern "C" int leann_recompute_last_timing(const leann_recompute *r, float *ms3) {
+    if (!r || !ms3) { leann_set_error("leann_recompute_last_timing: null argument"); return LEANN_ERR_INVALID; }
+    ms3[0] = r->last_ms[0]; ms3[1] = r->last_ms[1]; ms3[2] = r->last_ms[2];
+    return LEANN_OK;
+}
 
 // materialise the embeddings of rows [row0, row0 + rows) into d_out [rows x ld] (tests / validation)
 extern "C" int leann_recompute_encode_device(const leann_recompute *r, uint64_t row0, uint64_t rows, float *d_out, void *stream) {
@@ -290,7 +296,7 @@ extern "C" int leann_recompute_encode_device(const leann_recompute *r, uint64_t 
 // scan.hip internals reused per chunk
 int leann_internal_scan_chunk(const float *E, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, uint32_t k,
                               const uint8_t *allow, uint64_t row0, float *S, uint64_t *cand, size_t cand_len, size_t seg_off,
-                              hipStream_t st, size_t *segs_out);
+                              hipStream_t st, size_t *segs_out, hipEvent_t mid = nullptr);
 int leann_internal_scan_finish(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k,
                                uint64_t key_offset, uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st);
 
@@ -325,17 +331,39 @@ extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, con
     HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
     size_t seg_off = 0;
     int rc = LEANN_OK;
+    std::vector<hipEvent_t> evs(n_chunks * 4 + 1);
+    for (auto &e : evs) HIP_CHECK_RET(hipEventCreate(&e));
     for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
         const size_t row0 = c * chunk, rows = std::min(chunk, r->n - row0);
+        (void)hipEventRecord(evs[c * 4 + 0], st);
         rc = launch_encode(r, row0, rows, E, st);
+        (void)hipEventRecord(evs[c * 4 + 1], st);
         size_t segs = 0;
         if (rc == LEANN_OK)
-            rc = leann_internal_scan_chunk(E, rows, r->d, r->ld, d_queries, nq, k, d_allow_mask, row0, S, candA, cand_len, seg_off, st, &segs);
+            rc = leann_internal_scan_chunk(E, rows, r->d, r->ld, d_queries, nq, k, d_allow_mask, row0, S, candA, cand_len, seg_off, st,
+                                           &segs, evs[c * 4 + 2]);
+        (void)hipEventRecord(evs[c * 4 + 3], st);
         seg_off += segs;
     }
     if (rc == LEANN_OK)
         rc = leann_internal_scan_finish(candA, candB, cand_len, total_segs, nq, k, r->key_offset, d_keys, d_scores, d_counts, st);
+    (void)hipEventRecord(evs[n_chunks * 4], st);
     (void)hipStreamSynchronize(st);
+    {
+        leann_recompute *rw = const_cast<leann_recompute *>(r);
+        rw->last_ms[0] = rw->last_ms[1] = rw->last_ms[2] = 0.f;
+        for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, evs[c * 4 + 0], evs[c * 4 + 1]) == hipSuccess) rw->last_ms[0] += ms;
+            if (hipEventElapsedTime(&ms, evs[c * 4 + 1], evs[c * 4 + 2]) == hipSuccess) rw->last_ms[1] += ms;
+            if (hipEventElapsedTime(&ms, evs[c * 4 + 2], evs[c * 4 + 3]) == hipSuccess) rw->last_ms[2] += ms;
+        }
+        if (n_chunks && rc == LEANN_OK) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, evs[(n_chunks - 1) * 4 + 3], evs[n_chunks * 4]) == hipSuccess) rw->last_ms[2] += ms;
+        }
+    }
+    for (auto &e : evs) (void)hipEventDestroy(e);
     (void)hipFree(E);
     (void)hipFree(S);
     (void)hipFree(candA);

@@ -179,10 +179,11 @@ __global__ void finalize_scan_kernel(const uint64_t *__restrict__ keys, uint32_t
 // one chunk: scores of rows [0, rows) of Xbase against all queries, per-segment top-k appended to cand
 int leann_internal_scan_chunk(const float *Xbase, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, uint32_t k,
                               const uint8_t *allow, uint64_t pos0, float *S, uint64_t *cand, size_t cand_len, size_t seg_off,
-                              hipStream_t st, size_t *segs_out) {
+                              hipStream_t st, size_t *segs_out, hipEvent_t mid = nullptr) {
     dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
     hipLaunchKernelGGL(score_mfma_kernel, g1, dim3(256), 0, st, Xbase, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld, d_queries,
                        (uint32_t)nq, (uint32_t)dims, (uint64_t)0, (uint32_t)rows, S);
+    if (mid) (void)hipEventRecord(mid, st);
     unsigned segs = (unsigned)((rows + SEG - 1) / SEG);
     hipLaunchKernelGGL(topk_scores_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, S, (uint32_t)rows, pos0, allow, k, cand,
                        (uint32_t)cand_len, (uint32_t)seg_off);
