@@ -25,6 +25,8 @@
 #include <numeric>
 
 #define NCMAX 128
+#define EXPCAP 256 // expanded nodes recorded per construction search (Vamana)
+#define PATHMAX 48 // of which at most this many path nodes join the prune candidates
 #define TRI_ELEMS (NCMAX * (NCMAX - 1) / 2)
 
 struct ListView {
@@ -53,18 +55,17 @@ __device__ __forceinline__ void list_ptr(const ListView &lv, uint32_t node, uint
 // (drop c if alpha * dist(c, kept) <= dist(c, p)).   256 threads.  Returns count in every thread;
 // kept candidate positions in s_sel[0..count).
 // ------------------------------------------------------------------------------------------------
-__device__ uint32_t prune_core(const float *__restrict__ X, uint32_t ld, const uint32_t *c_id, const float *c_d,
-                               uint32_t nc, uint32_t limit, float alpha, float *tri /* TRI_ELEMS floats, LDS */,
-                               uint32_t *s_sel /* [64] LDS */, uint32_t *s_cnt /* LDS */) {
+template <int TS> // per-thread tile TS x TS; the 16 x 16 thread grid covers 16*TS candidates
+__device__ __forceinline__ void gram_lower(const float *__restrict__ X, uint32_t ld, const uint32_t *c_id, uint32_t nc,
+                                           float *tri, float *stage) {
     constexpr int KC = 32, LDW = NCMAX + 1;
-    float *stage = tri; // [KC][LDW] aliased: dead before tri is written
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const bool active = tx <= ty; // 8x8 blocks that touch the lower triangle
-    float acc[8][8];
+    const bool active = tx <= ty && (uint32_t)(ty * TS) < nc; // blocks that touch the lower triangle of the nc x nc matrix
+    float acc[TS][TS];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < TS; i++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = 0.f;
+        for (int j = 0; j < TS; j++) acc[i][j] = 0.f;
     const int srow = tid >> 1, shalf = tid & 1;
     const float *rowp = (srow < (int)nc) ? X + (size_t)c_id[srow] * ld : nullptr;
     for (uint32_t k0 = 0; k0 < ld; k0 += KC) {
@@ -75,41 +76,53 @@ __device__ uint32_t prune_core(const float *__restrict__ X, uint32_t ld, const u
             v[e] = (rowp && j < ld) ? *reinterpret_cast<const float4 *>(rowp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads(); // previous chunk fully consumed
+        if (srow < 16 * TS) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int kk = shalf * 16 + e * 4;
-            stage[(kk + 0) * LDW + srow] = v[e].x;
-            stage[(kk + 1) * LDW + srow] = v[e].y;
-            stage[(kk + 2) * LDW + srow] = v[e].z;
-            stage[(kk + 3) * LDW + srow] = v[e].w;
+            for (int e = 0; e < 4; e++) {
+                int kk = shalf * 16 + e * 4;
+                stage[(kk + 0) * LDW + srow] = v[e].x;
+                stage[(kk + 1) * LDW + srow] = v[e].y;
+                stage[(kk + 2) * LDW + srow] = v[e].z;
+                stage[(kk + 3) * LDW + srow] = v[e].w;
+            }
         }
         __syncthreads();
         if (active) {
 #pragma unroll 4
             for (int kk = 0; kk < KC; kk++) {
-                float a[8], b[8];
+                float a[TS], b[TS];
 #pragma unroll
-                for (int i = 0; i < 8; i++) a[i] = stage[kk * LDW + ty * 8 + i];
+                for (int i = 0; i < TS; i++) a[i] = stage[kk * LDW + ty * TS + i];
 #pragma unroll
-                for (int j = 0; j < 8; j++) b[j] = stage[kk * LDW + tx * 8 + j];
+                for (int j = 0; j < TS; j++) b[j] = stage[kk * LDW + tx * TS + j];
 #pragma unroll
-                for (int i = 0; i < 8; i++)
+                for (int i = 0; i < TS; i++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < TS; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
             }
         }
     }
     __syncthreads(); // stage dead; tri may be written
     if (active) {
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < TS; i++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                int r = ty * 8 + i, c = tx * 8 + j;
+            for (int j = 0; j < TS; j++) {
+                int r = ty * TS + i, c = tx * TS + j;
                 if (c < r && r < (int)nc) tri[r * (r - 1) / 2 + c] = 1.0f - acc[i][j];
             }
     }
     __syncthreads();
+}
+
+__device__ uint32_t prune_core(const float *__restrict__ X, uint32_t ld, const uint32_t *c_id, const float *c_d,
+                               uint32_t nc, uint32_t limit, float alpha, float *tri /* TRI_ELEMS floats, LDS */,
+                               uint32_t *s_sel /* [64] LDS */, uint32_t *s_cnt /* LDS */) {
+    float *stage = tri; // [KC][LDW] aliased: dead before tri is written
+    const int tid = threadIdx.x;
+    if (nc <= 32) gram_lower<2>(X, ld, c_id, nc, tri, stage);       // work ~ nc^2: small lists use small tiles
+    else if (nc <= 64) gram_lower<4>(X, ld, c_id, nc, tri, stage);
+    else gram_lower<8>(X, ld, c_id, nc, tri, stage);
     if (tid < 64) { // wave 0: sequential walk over candidates, lanes = kept slots
         uint32_t ns = 0;
         int my = -1;
@@ -140,21 +153,64 @@ __global__ void __launch_bounds__(256) select_kernel(const float *__restrict__ X
                                                      const uint32_t *__restrict__ q_rows, uint32_t nq, uint32_t level,
                                                      const uint64_t *__restrict__ cand_keys, const float *__restrict__ cand_d,
                                                      const uint32_t *__restrict__ cand_cnt, uint32_t efc, uint32_t msel,
-                                                     float alpha, uint64_t *__restrict__ prop_key, uint32_t *__restrict__ prop_src) {
+                                                     float alpha, uint64_t *__restrict__ prop_key, uint32_t *__restrict__ prop_src,
+                                                     const uint64_t *__restrict__ exp_keys, const uint32_t *__restrict__ exp_cnt,
+                                                     uint32_t exp_cap) {
     __shared__ float tri[TRI_ELEMS];
     __shared__ uint32_t c_id[NCMAX];
     __shared__ float c_d[NCMAX];
     __shared__ uint32_t s_sel[64];
     __shared__ uint32_t s_cnt;
+    __shared__ uint64_t pkey[EXPCAP];
     const uint32_t qi = blockIdx.x;
     if (qi >= nq) return;
     const uint32_t q = q_rows[qi];
-    const uint32_t nc = min(min(cand_cnt[qi], efc), (uint32_t)NCMAX);
+    uint32_t nc = min(min(cand_cnt[qi], efc), (uint32_t)NCMAX);
     for (uint32_t i = threadIdx.x; i < NCMAX; i += 256) {
         c_id[i] = i < nc ? (uint32_t)cand_keys[(size_t)qi * efc + i] : 0u;
         c_d[i] = i < nc ? cand_d[(size_t)qi * efc + i] : 0.f;
     }
     __syncthreads();
+    if (exp_keys && nc > 0) {
+        // Vamana: prune over the visited set V = final beam  ∪  nodes expanded on the way from the medoid
+        // (DiskANN Alg. 2/3).  Path nodes are the expanded entries farther than the beam's worst entry; they
+        // supply the long-range edges that keep a single-level graph navigable.
+        const uint64_t wmax = ((uint64_t)f32_orderable(c_d[nc - 1]) << 32) | c_id[nc - 1];
+        const uint32_t np = min(exp_cnt[qi], min(exp_cap, (uint32_t)EXPCAP));
+        for (uint32_t i = threadIdx.x; i < EXPCAP; i += 256) {
+            uint64_t key = i < np ? exp_keys[(size_t)qi * exp_cap + i] : ~0ull;
+            pkey[i] = (key != ~0ull && key > wmax) ? key : ~0ull;
+        }
+        for (int size = 2; size <= EXPCAP; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                if (threadIdx.x < EXPCAP / 2) {
+                    int i = threadIdx.x;
+                    int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                    bool up = ((lo & size) == 0);
+                    uint64_t a = pkey[lo], b2 = pkey[hi];
+                    if ((a > b2) == up) { pkey[lo] = b2; pkey[hi] = a; }
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t n_path = 0;
+            while (n_path < EXPCAP && pkey[n_path] != ~0ull) n_path++;
+            s_cnt = n_path;
+        }
+        __syncthreads();
+        const uint32_t n_path = s_cnt;
+        const uint32_t take = min(n_path, (uint32_t)PATHMAX);
+        const uint32_t keep = min(nc, (uint32_t)NCMAX - take);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < take; t += 256) { // even subsample keeps near and far path nodes
+            const uint64_t key = pkey[(uint64_t)t * n_path / take];
+            c_id[keep + t] = (uint32_t)key;
+            c_d[keep + t] = orderable_f32((uint32_t)(key >> 32));
+        }
+        nc = keep + take;
+        __syncthreads();
+    }
     uint32_t ns = prune_core(X, ld, c_id, c_d, nc, msel, alpha, tri, s_sel, &s_cnt);
     uint32_t *ids; float *ds; uint32_t cap;
     list_ptr(lv, q, level, &ids, &ds, &cap);
@@ -304,6 +360,7 @@ struct Builder {
     uint64_t *candU_keys = nullptr; float *candU_d = nullptr; uint32_t *candU_cnt = nullptr; uint32_t *d_rowsU = nullptr;
     uint64_t *prop_key = nullptr, *prop_key2 = nullptr; uint32_t *prop_src = nullptr, *prop_src2 = nullptr;
     uint32_t *seg_start = nullptr, *nseg = nullptr;
+    uint64_t *exp_keys = nullptr; uint32_t *exp_cnt = nullptr; // Vamana only
     void *cub_tmp = nullptr; size_t cub_bytes = 0;
     hipStream_t st = nullptr;
 };
@@ -318,12 +375,12 @@ struct Builder {
     } while (0)
 
 static int link_level(Builder &b, const uint32_t *d_rows, uint32_t nq, uint32_t level, const uint64_t *ck, const float *cd,
-                      const uint32_t *cc) {
+                      const uint32_t *cc, const uint64_t *ek = nullptr, const uint32_t *ec = nullptr) {
     leann_backend *h = b.h;
     const uint32_t efc = h->efc, msel = h->g.M; // M new links per point on every level (Malkov Alg. 1)
     const float alpha = h->kind == LEANN_BACKEND_DISKANN ? h->alpha : 0.f;
     hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, d_rows, nq, level, ck, cd, cc,
-                       efc, msel, alpha, b.prop_key, b.prop_src);
+                       efc, msel, alpha, b.prop_key, b.prop_src, ek, ec, (uint32_t)EXPCAP);
     const uint32_t num = nq * msel;
     size_t tmp = b.cub_bytes;
     BCHECK(hipcub::DeviceRadixSort::SortPairs(b.cub_tmp, tmp, b.prop_key, b.prop_key2, b.prop_src, b.prop_src2, (int)num, 0, 64, b.st));
@@ -354,6 +411,10 @@ static int builder_alloc_scratch(Builder &b, size_t bmax) {
     BCHECK(hipMalloc((void **)&b.prop_src2, bmax * msel * 4));
     BCHECK(hipMalloc((void **)&b.seg_start, bmax * msel * 4));
     BCHECK(hipMalloc((void **)&b.nseg, 16));
+    if (h->kind == LEANN_BACKEND_DISKANN) {
+        BCHECK(hipMalloc((void **)&b.exp_keys, bmax * EXPCAP * 8));
+        BCHECK(hipMalloc((void **)&b.exp_cnt, bmax * 4));
+    }
     size_t tmp = 0;
     BCHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, b.prop_key, b.prop_key2, b.prop_src, b.prop_src2,
                                               (int)(bmax * msel), 0, 64, b.st));
@@ -363,7 +424,7 @@ static int builder_alloc_scratch(Builder &b, size_t bmax) {
 }
 static void builder_free_scratch(Builder &b) {
     void *ps[] = {b.cand_keys, b.cand_d, b.cand_cnt, b.candU_keys, b.candU_d, b.candU_cnt, b.d_rowsU, b.prop_key, b.prop_key2,
-                  b.prop_src, b.prop_src2, b.seg_start, b.nseg, b.cub_tmp, b.d_order, b.adjd0, b.adjdU};
+                  b.prop_src, b.prop_src2, b.seg_start, b.nseg, b.cub_tmp, b.d_order, b.adjd0, b.adjdU, b.exp_keys, b.exp_cnt};
     for (void *p : ps) (void)hipFree(p);
 }
 
@@ -419,6 +480,9 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
             a.out_keys = b.cand_keys;
             a.out_dists = b.cand_d;
             a.out_counts = b.cand_cnt;
+            a.out_expanded = b.exp_keys; // null for HNSW
+            a.out_nexp = b.exp_cnt;
+            a.exp_cap = EXPCAP;
             int rc = leann_internal_launch_search(h, a, b.st);
             if (rc) return rc;
         }
@@ -428,7 +492,7 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
                                 b.candU_cnt + j.off);
             if (rc) return rc;
         }
-        int rc = link_level(b, b.d_order + s, (uint32_t)B, 0, b.cand_keys, b.cand_d, b.cand_cnt);
+        int rc = link_level(b, b.d_order + s, (uint32_t)B, 0, b.cand_keys, b.cand_d, b.cand_cnt, b.exp_keys, b.exp_cnt);
         if (rc) return rc;
         // ---- entry point / top level (sequential semantics of hnsw.rs:128-130 within the batch) --
         if (hnsw)

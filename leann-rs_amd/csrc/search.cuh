@@ -43,6 +43,9 @@ struct SearchArgs {
     float *out_dists;         // [nq x k]
     uint32_t *out_counts;     // [nq]
     uint32_t *out_stats;      // [nq x 4] evals, hops0, hopsU, 1 if the HBM table was used  (optional)
+    uint64_t *out_expanded;   // optional [nq x exp_cap]: (orderable(dist) << 32 | id) of every node expanded on the
+    uint32_t *out_nexp;       //          target level, in expansion order (Vamana's visited set V), and its count
+    uint32_t exp_cap;
     unsigned long long *gpool; // [GPOOL_TABLES << GPOOL_BITS]
     uint32_t *gpool_lock;     // [GPOOL_TABLES] 0 = free
     uint32_t *gpool_ctr;      // [0] acquire ticket, [1] generation counter
@@ -157,7 +160,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         best = make_key(dd[0], g.entry); // every wave computes the same value
     }
 
-    uint32_t wsize = 0;
+    uint32_t wsize = 0, level_hops = 0;
     int cur = 0;
     bool aborted = false;
     for (int lv = (int)g.max_level; lv >= (int)a.target_level; --lv) {
@@ -191,6 +194,8 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
             // ---- phase B: adjacency list through the visited table (wave 0) ------------------
             if (wave == 0) {
                 const uint32_t node = key_id(Wc[sel]);
+                if (a.out_expanded && lv == (int)a.target_level && lane == 0 && hop < a.exp_cap)
+                    a.out_expanded[(size_t)qi * a.exp_cap + hop] = ((Wc[sel] >> 32) << 32) | node;
                 const uint32_t *adj = lv == 0 ? g.adj0 + (size_t)node * g.M0
                                               : g.adjU + ((size_t)g.upper_off[node] + (uint32_t)(lv - 1)) * g.M;
                 uint32_t n_new = 0;
@@ -297,6 +302,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
             cur ^= 1;
             hop++;
         }
+        level_hops = hop;
         if (aborted) break;
         best = W0[cur * efp] & ~1ull;
         __syncthreads(); // everyone has read `best` before the next level rewrites W[0]
@@ -336,6 +342,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     }
     if (tid == 0) {
         a.out_counts[qi] = nout;
+        if (a.out_nexp) a.out_nexp[qi] = min(level_hops, a.exp_cap);
         if (a.out_stats) {
             a.out_stats[(size_t)qi * 4 + 0] = n_evals;
             a.out_stats[(size_t)qi * 4 + 1] = hops0;
