@@ -180,13 +180,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists in the product path)")
+    if torch.cuda.device_count() < world and os.environ.get("LEANN_BENCH_DIST_BACKEND") == "gloo":
+        local_rank = 0  # rehearsal of the N > 1 path on a one-GPU box: ranks share device 0, exchange over gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+        backend_name = os.environ.get("LEANN_BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend_name)
 
     import leann_rs_amd as la  # after torch: binds to the HIP runtime torch already loaded
     from leann_rs_amd.shard import exchange_topk, _hip_merge as hip_merge
