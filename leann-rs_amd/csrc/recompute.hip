@@ -84,21 +84,58 @@ __global__ void tile_weights_kernel(const uint16_t *__restrict__ W, uint32_t h, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// encode_normalize_kernel<CT>: 512 threads = 8 waves; workgroup tile = 128 passages x (CT*4*32) columns
-// (CT col tiles of 32 per wave, 4 column groups, 2 row halves of 64 passages).  d <= CT*128.
-// LDS: sF[128][hp + 8] bf16 (whole K, loaded once) + 2 x sW[dp][24] bf16 (one 16-deep k-step each).
+// Query-side projection for the fused search: G = W Q^T  [h x 64] in f32 (k-ordered fmaf chain), split
+// into three bf16 pieces g = hi + lo + lo2 (24 mantissa bits: since the features are exactly bf16, the
+// three bf16 MFMAs F*hi + F*lo + F*lo2 reproduce the f32 products F*g), tiled like the weights:
+// Gp[kstep][piece*64 + q][16].  By associativity  <l2norm(W^T f), q> = <f, W q> / ||W^T f||, so the
+// d-dimensional scoring GEMM against materialised embeddings becomes an h-dimensional one fused into
+// the encode loop, and the embeddings never leave the registers.
 // ------------------------------------------------------------------------------------------------
-template <int CT>
-__global__ void __launch_bounds__(512) encode_normalize_kernel(const uint16_t *__restrict__ F, uint64_t n, uint32_t h,
-                                                               uint32_t hp, const uint16_t *__restrict__ Wp, uint32_t d,
-                                                               uint32_t ld_out, float *__restrict__ E) {
-    constexpr int DP = CT * 128;   // padded columns
-    constexpr int WSTRIDE = 24;    // bf16 per column in a staged k-step (16 + 8 pad: conflict-free b128 reads)
+__global__ void project_queries_kernel(const uint16_t *__restrict__ W, uint32_t h, uint32_t hp, uint32_t d,
+                                       const float *__restrict__ Q, uint32_t ldq, uint32_t nq, uint16_t *__restrict__ Gp) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; // (k, q)
+    if (idx >= hp * 64) return;
+    const uint32_t k = idx / 64, q = idx % 64;
+    float g = 0.f;
+    if (k < h && q < nq) {
+        const uint16_t *wk = W + (size_t)k * d;
+        const float *qv = Q + (size_t)q * ldq;
+        for (uint32_t j = 0; j < d; j++) g = fmaf(__uint_as_float((uint32_t)wk[j] << 16), qv[j], g);
+    }
+    const uint16_t hi = f32_to_bf16_rne(g);
+    const float r1 = g - __uint_as_float((uint32_t)hi << 16);
+    const uint16_t lo = f32_to_bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float((uint32_t)lo << 16);
+    const uint16_t lo2 = f32_to_bf16_rne(r2);
+    const uint32_t ks = k / 16, kk = k % 16;
+    uint16_t *base = Gp + (size_t)ks * 192 * 16;
+    base[(0 * 64 + q) * 16 + kk] = hi;
+    base[(1 * 64 + q) * 16 + kk] = lo;
+    base[(2 * 64 + q) * 16 + kk] = lo2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode_kernel<CT, FUSED>: 512 threads = 8 waves; workgroup tile = 128 passages x (CT*4*32) columns
+// (CT col tiles of 32 per wave, 4 column groups, 2 row halves of 64 passages).  d <= CT*128.
+// LDS: sF[128][hp + 8] bf16 (whole K, loaded once) + 2 x sW[DP (+192)][24] bf16 (one 16-deep k-step each).
+//   FUSED = false: E = l2norm(F W) stored as f32 (validation / leann_recompute_encode_device)
+//   FUSED = true : nothing but S[q][passage] = <f, W q> / ||W^T f|| leaves the workgroup; each wave adds
+//                  3 MFMAs per k-step (hi/lo/lo2 pieces) for one 32-query x 32-passage score tile,
+//                  reusing the feature fragment it already holds as the B operand.
+// ------------------------------------------------------------------------------------------------
+template <int CT, bool FUSED>
+__global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict__ F, uint64_t n, uint32_t h, uint32_t hp,
+                                                     const uint16_t *__restrict__ Wp, uint32_t d, uint32_t ld_out,
+                                                     float *__restrict__ E, const uint16_t *__restrict__ Gp, uint32_t nq,
+                                                     float *__restrict__ S, uint32_t n_rows_s) {
+    constexpr int DP = CT * 128;              // padded columns of W
+    constexpr int DPX = DP + (FUSED ? 192 : 0); // + three 64-query pieces of G
+    constexpr int WSTRIDE = 24;               // bf16 per column in a staged k-step (16 + 8 pad: conflict-free b128 reads)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t fstride = hp + 8; // bf16 elements per sF row
     uint16_t *sF = reinterpret_cast<uint16_t *>(smem);
-    uint16_t *sW = sF + 128 * fstride;                       // [2][DP][WSTRIDE]
-    float *sN = reinterpret_cast<float *>(sW + 2 * DP * WSTRIDE); // [4 col groups][128 rows] partial sum of squares
+    uint16_t *sW = sF + 128 * fstride;                              // [2][DPX][WSTRIDE]
+    float *sN = reinterpret_cast<float *>(sW + 2 * DPX * WSTRIDE);  // [4 col groups][128 rows] partial sum of squares
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int rhalf = wave >> 2, cgrp = wave & 3;
@@ -119,21 +156,32 @@ __global__ void __launch_bounds__(512) encode_normalize_kernel(const uint16_t *_
         }
         *reinterpret_cast<uint4 *>(sF + r * fstride + k8) = v;
     }
-    auto stage_w = [&](int buf, uint32_t ks) { // 16 k x DP columns, contiguous in Wp
+    auto stage_w = [&](int buf, uint32_t ks) { // 16 k x DPX columns; W part and G part are contiguous per k-step
         const uint4 *src = reinterpret_cast<const uint4 *>(Wp + (size_t)ks * DP * 16);
-        uint16_t *dst = sW + buf * DP * WSTRIDE;
+        uint16_t *dst = sW + buf * DPX * WSTRIDE;
         for (uint32_t idx = tid; idx < DP * 2; idx += 512) { // 2 x 16 B per column
             const uint32_t col = idx >> 1, half = idx & 1;
             *reinterpret_cast<uint4 *>(dst + col * WSTRIDE + half * 8) = src[idx];
         }
+        if (FUSED) {
+            const uint4 *gs = reinterpret_cast<const uint4 *>(Gp + (size_t)ks * 192 * 16);
+            for (uint32_t idx = tid; idx < 192 * 2; idx += 512) {
+                const uint32_t col = idx >> 1, half = idx & 1;
+                *reinterpret_cast<uint4 *>(dst + (DP + col) * WSTRIDE + half * 8) = gs[idx];
+            }
+        }
     };
     f32x16 acc[2][CT];
+    f32x16 accs; // FUSED: scores of query tile (cgrp & 1) x passage tile (2*rhalf + (cgrp >> 1))
+#pragma unroll
+    for (int i = 0; i < 16; i++) accs[i] = 0.f;
 #pragma unroll
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[rt][ct][i] = 0.f;
+    const int st = cgrp >> 1, qt = cgrp & 1;
 
     const uint32_t nks = hp / 16;
     stage_w(0, 0);
@@ -141,7 +189,7 @@ __global__ void __launch_bounds__(512) encode_normalize_kernel(const uint16_t *_
     for (uint32_t ks = 0; ks < nks; ks++) {
         const int buf = ks & 1;
         if (ks + 1 < nks) stage_w(buf ^ 1, ks + 1); // next k-step lands while this one is consumed
-        const uint16_t *w = sW + buf * DP * WSTRIDE;
+        const uint16_t *w = sW + buf * DPX * WSTRIDE;
         bf16x8 a[2], b[CT];
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
@@ -154,10 +202,18 @@ __global__ void __launch_bounds__(512) encode_normalize_kernel(const uint16_t *_
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+        if (FUSED) {
+            const bf16x8 fb = st ? a[1] : a[0]; // B operand: B[k][j = passage]  (same bytes as the A fragment of F)
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const bf16x8 g = *reinterpret_cast<const bf16x8 *>(w + (DP + p * 64 + qt * 32 + l31) * WSTRIDE + lh * 8);
+                accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, fb, accs, 0, 0, 0); // C[i = query][j = passage]
+            }
+        }
         __syncthreads();
     }
 
-    // ---- fused epilogue: row norms (candle.rs:218-225) then one f32 store of the normalised tile ------
+    // ---- fused epilogue: row norms (candle.rs:218-225) ---------------------------------------------------
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int rt = 0; rt < 2; rt++) {
@@ -176,6 +232,22 @@ __global__ void __launch_bounds__(512) encode_normalize_kernel(const uint16_t *_
         }
     }
     __syncthreads();
+    if (FUSED) {
+        // score tile: rows (regs) = queries, col (lane & 31) = passage -> 128-B coalesced stores into S[q][passage]
+        const int r = rhalf * 64 + st * 32 + l31;
+        const uint64_t row = row_base + r;
+        const float ss = ((sN[r] + sN[128 + r]) + (sN[256 + r] + sN[384 + r]));
+        float nrm = sqrtf(ss);
+        nrm = nrm < 1e-12f ? 1e-12f : nrm;
+        if (row < n) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const uint32_t q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (q < nq) S[(size_t)q * n_rows_s + row] = accs[reg] / nrm;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int rt = 0; rt < 2; rt++) {
 #pragma unroll
@@ -189,7 +261,7 @@ __global__ void __launch_bounds__(512) encode_normalize_kernel(const uint16_t *_
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
                     const uint32_t col = (cgrp * CT + ct) * 32 + l31;
-                    if (col < ld_out) E[(size_t)(row - 0) * ld_out + col] = col < d ? acc[rt][ct][reg] / nrm : 0.f;
+                    if (col < ld_out) E[(size_t)row * ld_out + col] = col < d ? acc[rt][ct][reg] / nrm : 0.f;
                 }
             }
         }
@@ -201,24 +273,34 @@ struct leann_recompute {
     int device = 0;
     const uint16_t *F = nullptr; // borrowed [n x h]
     uint16_t *Wp = nullptr;      // owned, tiled
+    uint16_t *Wraw = nullptr;    // owned copy [h x d] (query projection)
     size_t n = 0, h = 0, hp = 0, d = 0, dp = 0, ld = 0;
     uint64_t key_offset = 0;
     int ct = 0;
     float last_ms[3] = {0, 0, 0}; // encode, score, top-k of the last search call (HIP events)
 };
 
-static size_t encode_lds_bytes(size_t hp, size_t dp) { return 128 * (hp + 8) * 2 + 2 * dp * 24 * 2 + 4 * 128 * 4; }
+static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { return 128 * (hp + 8) * 2 + 2 * (dp + (fused ? 192 : 0)) * 24 * 2 + 4 * 128 * 4; }
 
-static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st) {
-    const size_t lds = encode_lds_bytes(r->hp, r->dp);
+static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st,
+                         const uint16_t *Gp = nullptr, uint32_t nq = 0, float *S = nullptr) {
+    const bool fused = Gp != nullptr;
+    const size_t lds = encode_lds_bytes(r->hp, r->dp, fused);
     const unsigned grid = (unsigned)((rows + 127) / 128);
     const uint16_t *F = r->F + row0 * r->h;
-#define LAUNCH_CT(CT)                                                                                                    \
-    do {                                                                                                                 \
-        HIP_CHECK_RET(hipFuncSetAttribute((const void *)encode_normalize_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          160 * 1024));                                                                  \
-        hipLaunchKernelGGL(encode_normalize_kernel<CT>, dim3(grid), dim3(512), lds, st, F, (uint64_t)rows, (uint32_t)r->h,       \
-                           (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E);                                  \
+#define LAUNCH_CT(CT)                                                                                                     \
+    do {                                                                                                                  \
+        if (fused) {                                                                                                      \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void *)encode_kernel<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              160 * 1024));                                                               \
+            hipLaunchKernelGGL((encode_kernel<CT, true>), dim3(grid), dim3(512), lds, st, F, (uint64_t)rows, (uint32_t)r->h,     \
+                               (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E, Gp, nq, S, (uint32_t)rows);     \
+        } else {                                                                                                          \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void *)encode_kernel<CT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              160 * 1024));                                                               \
+            hipLaunchKernelGGL((encode_kernel<CT, false>), dim3(grid), dim3(512), lds, st, F, (uint64_t)rows, (uint32_t)r->h,    \
+                               (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E, Gp, nq, S, (uint32_t)rows);     \
+        }                                                                                                                 \
     } while (0)
     switch (r->ct) {
         case 1: LAUNCH_CT(1); break;
@@ -259,12 +341,14 @@ extern "C" int leann_recompute_create(const uint16_t *d_features, size_t n, size
     r->ct = ct;
     r->dp = (size_t)ct * 128;
     r->key_offset = key_offset;
-    if (encode_lds_bytes(r->hp, r->dp) > 160 * 1024) {
+    if (encode_lds_bytes(r->hp, r->dp, true) > 160 * 1024) {
         delete r;
         leann_set_error("recompute: feature width %zu x dims %zu exceeds the 160 KiB LDS tile", h, dims);
         return LEANN_ERR_INVALID;
     }
     HIP_CHECK_RET(hipMalloc((void **)&r->Wp, r->hp * r->dp * 2));
+    HIP_CHECK_RET(hipMalloc((void **)&r->Wraw, h * dims * 2));
+    HIP_CHECK_RET(hipMemcpy(r->Wraw, d_weights, h * dims * 2, hipMemcpyDeviceToDevice));
     const uint32_t total = (uint32_t)(r->hp * r->dp);
     hipLaunchKernelGGL(tile_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, nullptr, d_weights, (uint32_t)h, (uint32_t)dims,
                        (uint32_t)r->hp, (uint32_t)r->dp, r->Wp);
@@ -276,6 +360,7 @@ extern "C" int leann_recompute_create(const uint16_t *d_features, size_t n, size
 extern "C" void leann_recompute_close(leann_recompute *r) {
     if (!r) return;
     (void)hipFree(r->Wp);
+    (void)hipFree(r->Wraw);
     delete r;
 }
 extern "C" size_t leann_recompute_len(const leann_recompute *r) { return r ? r->n : 0; }
@@ -294,13 +379,14 @@ extern "C" int leann_recompute_encode_device(const leann_recompute *r, uint64_t 
 }
 
 // scan.hip internals reused per chunk
-int leann_internal_scan_chunk(const float *E, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, uint32_t k,
-                              const uint8_t *allow, uint64_t row0, float *S, uint64_t *cand, size_t cand_len, size_t seg_off,
-                              hipStream_t st, size_t *segs_out, hipEvent_t mid = nullptr);
+int leann_internal_topk_chunk(const float *S, size_t rows, size_t nq, uint32_t k, const uint8_t *allow, uint64_t pos0, uint64_t *cand,
+                              size_t cand_len, size_t seg_off, hipStream_t st, size_t *segs_out, uint64_t *best);
 int leann_internal_scan_finish(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k,
                                uint64_t key_offset, uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st);
 
 // RecomputeSearcher::search arithmetic for a batch of queries — recompute.rs:86-109 on the GPU.
+// Per tile of <= 64 queries: G = W Q^T once, then per chunk of passages ONE fused kernel (encode GEMM,
+// row norms, feature-space scoring) + segment top-k; the embeddings are never written anywhere.
 extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, const float *d_queries, size_t nq, size_t top_k,
                                                    const uint8_t *d_allow_mask, uint64_t *d_keys, float *d_scores,
                                                    uint32_t *d_counts, void *stream) {
@@ -313,60 +399,76 @@ extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, con
     hipStream_t st = (hipStream_t)stream;
     const uint32_t k = (uint32_t)top_k;
     const size_t SEGSZ = 2048;
-    // chunk so that E (rows x ld f32) <= ~3 GiB and the score slab (nq x rows f32) <= 2 GiB
-    size_t chunk = std::min<size_t>(((size_t)3 << 30) / (r->ld * 4), ((size_t)1 << 29) / std::max<size_t>(nq, 1));
-    chunk = std::max<size_t>(SEGSZ, chunk / SEGSZ * SEGSZ);
-    chunk = std::min(chunk, (std::max<size_t>(r->n, 1) + SEGSZ - 1) / SEGSZ * SEGSZ);
-    const size_t n_chunks = r->n ? (r->n + chunk - 1) / chunk : 0;
-    size_t total_segs = 0;
-    for (size_t c = 0; c < n_chunks; c++) total_segs += (std::min(chunk, r->n - c * chunk) + SEGSZ - 1) / SEGSZ;
+    // geometric chunk schedule 128k, 512k, 2M, 4M, 4M ... : the first small chunks fix the running k-th best, after which
+    // topk_scores_kernel skips almost every segment unsorted
+    std::vector<std::pair<size_t, size_t>> chunks; // (row0, rows)
+    {
+        size_t pos = 0, len = (size_t)128 << 10;
+        while (pos < r->n) {
+            size_t rows = std::min(len, r->n - pos);
+            chunks.emplace_back(pos, rows);
+            pos += rows;
+            len = std::min<size_t>(len * 4, (size_t)4 << 20);
+        }
+    }
+    const size_t n_chunks = chunks.size();
+    size_t chunk = 0, total_segs = 0;
+    for (auto &c : chunks) { chunk = std::max(chunk, c.second); total_segs += (c.second + SEGSZ - 1) / SEGSZ; }
+    chunk = std::max<size_t>(chunk, SEGSZ);
     total_segs = std::max<size_t>(total_segs, 1);
     const size_t cand_len = std::max<size_t>(total_segs * k, k);
-    float *E = nullptr, *S = nullptr;
-    uint64_t *candA = nullptr, *candB = nullptr;
-    HIP_CHECK_RET(hipMalloc((void **)&E, chunk * r->ld * 4));
-    HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * nq * chunk));
+    float *S = nullptr;
+    uint16_t *Gp = nullptr;
+    uint64_t *candA = nullptr, *candB = nullptr, *best = nullptr;
+    HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * 64 * chunk));
+    HIP_CHECK_RET(hipMalloc((void **)&Gp, r->hp * 192 * 2));
     HIP_CHECK_RET(hipMalloc((void **)&candA, sizeof(uint64_t) * nq * cand_len));
     HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
+    HIP_CHECK_RET(hipMalloc((void **)&best, sizeof(uint64_t) * nq * k));
     HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
-    size_t seg_off = 0;
+    HIP_CHECK_RET(hipMemsetAsync(best, 0xFF, sizeof(uint64_t) * nq * k, st));
     int rc = LEANN_OK;
-    std::vector<hipEvent_t> evs(n_chunks * 4 + 1);
+    const size_t n_tiles = (nq + 63) / 64;
+    std::vector<hipEvent_t> evs(n_tiles * n_chunks * 3 + 1);
     for (auto &e : evs) HIP_CHECK_RET(hipEventCreate(&e));
-    for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
-        const size_t row0 = c * chunk, rows = std::min(chunk, r->n - row0);
-        (void)hipEventRecord(evs[c * 4 + 0], st);
-        rc = launch_encode(r, row0, rows, E, st);
-        (void)hipEventRecord(evs[c * 4 + 1], st);
-        size_t segs = 0;
-        if (rc == LEANN_OK)
-            rc = leann_internal_scan_chunk(E, rows, r->d, r->ld, d_queries, nq, k, d_allow_mask, row0, S, candA, cand_len, seg_off, st,
-                                           &segs, evs[c * 4 + 2]);
-        (void)hipEventRecord(evs[c * 4 + 3], st);
-        seg_off += segs;
+    size_t ei = 0;
+    for (size_t q0 = 0; q0 < nq && rc == LEANN_OK; q0 += 64) {
+        const uint32_t nqt = (uint32_t)std::min<size_t>(64, nq - q0);
+        hipLaunchKernelGGL(project_queries_kernel, dim3((unsigned)((r->hp * 64 + 255) / 256)), dim3(256), 0, st, r->Wraw, (uint32_t)r->h,
+                           (uint32_t)r->hp, (uint32_t)r->d, d_queries + q0 * r->d, (uint32_t)r->d, nqt, Gp);
+        size_t seg_off = 0;
+        for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
+            const size_t row0 = chunks[c].first, rows = chunks[c].second;
+            (void)hipEventRecord(evs[ei++], st);
+            rc = launch_encode(r, row0, rows, nullptr, st, Gp, nqt, S);
+            (void)hipEventRecord(evs[ei++], st);
+            size_t segs = 0;
+            if (rc == LEANN_OK)
+                rc = leann_internal_topk_chunk(S, rows, nqt, k, d_allow_mask, row0, candA + q0 * cand_len, cand_len, seg_off, st, &segs,
+                                               best + q0 * k);
+            (void)hipEventRecord(evs[ei++], st);
+            seg_off += segs;
+        }
     }
     if (rc == LEANN_OK)
         rc = leann_internal_scan_finish(candA, candB, cand_len, total_segs, nq, k, r->key_offset, d_keys, d_scores, d_counts, st);
-    (void)hipEventRecord(evs[n_chunks * 4], st);
+    (void)hipEventRecord(evs[ei], st);
     (void)hipStreamSynchronize(st);
     {
         leann_recompute *rw = const_cast<leann_recompute *>(r);
         rw->last_ms[0] = rw->last_ms[1] = rw->last_ms[2] = 0.f;
-        for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, evs[c * 4 + 0], evs[c * 4 + 1]) == hipSuccess) rw->last_ms[0] += ms;
-            if (hipEventElapsedTime(&ms, evs[c * 4 + 1], evs[c * 4 + 2]) == hipSuccess) rw->last_ms[1] += ms;
-            if (hipEventElapsedTime(&ms, evs[c * 4 + 2], evs[c * 4 + 3]) == hipSuccess) rw->last_ms[2] += ms;
+        float ms = 0.f;
+        for (size_t i = 0; i + 2 < ei + 1 && rc == LEANN_OK; i += 3) {
+            if (hipEventElapsedTime(&ms, evs[i], evs[i + 1]) == hipSuccess) rw->last_ms[0] += ms;     // fused encode + score
+            if (hipEventElapsedTime(&ms, evs[i + 1], evs[i + 2]) == hipSuccess) rw->last_ms[2] += ms; // segment top-k
         }
-        if (n_chunks && rc == LEANN_OK) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, evs[(n_chunks - 1) * 4 + 3], evs[n_chunks * 4]) == hipSuccess) rw->last_ms[2] += ms;
-        }
+        if (ei >= 3 && rc == LEANN_OK && hipEventElapsedTime(&ms, evs[ei - 1], evs[ei]) == hipSuccess) rw->last_ms[2] += ms;
     }
     for (auto &e : evs) (void)hipEventDestroy(e);
-    (void)hipFree(E);
     (void)hipFree(S);
+    (void)hipFree(Gp);
     (void)hipFree(candA);
     (void)hipFree(candB);
+    (void)hipFree(best);
     return rc;
 }

@@ -115,13 +115,18 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t *k, int n /* power of 
 }
 
 // scores S[q][n_rows] -> cand[q][seg][k]; key = ~orderable(score) << 32 | (row0 + row)   (position < 2^32)
+// `best` (optional): per query the k best keys seen in earlier chunks, ascending; best[q][k-1] is a bound that
+// every member of the final top-k must beat, so a segment without any key below it is skipped unsorted
+// (after a few hundred thousand rows that is > 95 % of the segments).
 __global__ void __launch_bounds__(256) topk_scores_kernel(const float *__restrict__ S, uint32_t n_rows, uint64_t row0,
                                                           const uint8_t *__restrict__ allow, uint32_t k,
                                                           uint64_t *__restrict__ cand, uint32_t cand_stride_q,
-                                                          uint32_t seg_off) {
+                                                          uint32_t seg_off, const uint64_t *__restrict__ best = nullptr) {
     __shared__ uint64_t keys[SEG];
     const uint32_t seg = blockIdx.x, q = blockIdx.y;
     const float *s = S + (size_t)q * n_rows;
+    const uint64_t bound = best ? best[(size_t)q * k + (k - 1)] : ~0ull;
+    int survivor = 0;
     for (int i = threadIdx.x; i < SEG; i += blockDim.x) {
         uint32_t row = seg * SEG + i;
         uint64_t key = ~0ull;
@@ -131,6 +136,12 @@ __global__ void __launch_bounds__(256) topk_scores_kernel(const float *__restric
             if (ok) key = ((uint64_t)(~f32_orderable(s[row])) << 32) | (uint32_t)pos;
         }
         keys[i] = key;
+        survivor |= (key < bound);
+    }
+    uint64_t *outp = cand + (size_t)q * cand_stride_q + (size_t)(seg_off + seg) * k;
+    if (!__syncthreads_or(survivor)) {
+        for (int i = threadIdx.x; i < (int)k; i += blockDim.x) outp[i] = ~0ull;
+        return;
     }
     bitonic_sort_lds(keys, SEG);
     uint64_t *out = cand + (size_t)q * cand_stride_q + (size_t)(seg_off + seg) * k;
@@ -187,6 +198,38 @@ int leann_internal_scan_chunk(const float *Xbase, size_t rows, size_t dims, size
     unsigned segs = (unsigned)((rows + SEG - 1) / SEG);
     hipLaunchKernelGGL(topk_scores_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, S, (uint32_t)rows, pos0, allow, k, cand,
                        (uint32_t)cand_len, (uint32_t)seg_off);
+    HIP_CHECK_RET(hipGetLastError());
+    *segs_out = segs;
+    return LEANN_OK;
+}
+// merge this chunk's segment winners into the running per-query best-k (ascending keys)
+__global__ void __launch_bounds__(256) update_best_kernel(const uint64_t *__restrict__ cand, uint32_t cand_stride_q, uint32_t seg_off,
+                                                          uint32_t n_segs, uint32_t k, uint64_t *__restrict__ best) {
+    __shared__ uint64_t keys[SEG];
+    const uint32_t q = blockIdx.x;
+    const uint64_t *src = cand + (size_t)q * cand_stride_q + (size_t)seg_off * k;
+    const uint32_t m = n_segs * k;
+    // running selection: fold the candidate list through the LDS sorter SEG - k keys at a time
+    for (int i = threadIdx.x; i < (int)k; i += blockDim.x) keys[i] = best[(size_t)q * k + i];
+    for (uint32_t base = 0; base < m; base += SEG - k) {
+        for (int i = threadIdx.x; i < SEG - (int)k; i += blockDim.x) {
+            uint32_t p = base + i;
+            keys[k + i] = p < m ? src[p] : ~0ull;
+        }
+        bitonic_sort_lds(keys, SEG);
+    }
+    for (int i = threadIdx.x; i < (int)k; i += blockDim.x) best[(size_t)q * k + i] = keys[i];
+}
+
+// segment top-k of a score slab S[nq][rows] (scores produced elsewhere, e.g. the fused recompute kernel);
+// `best` [nq x k] carries the running best keys across chunks (0xFF-filled before the first chunk).
+int leann_internal_topk_chunk(const float *S, size_t rows, size_t nq, uint32_t k, const uint8_t *allow, uint64_t pos0, uint64_t *cand,
+                              size_t cand_len, size_t seg_off, hipStream_t st, size_t *segs_out, uint64_t *best) {
+    unsigned segs = (unsigned)((rows + SEG - 1) / SEG);
+    hipLaunchKernelGGL(topk_scores_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, S, (uint32_t)rows, pos0, allow, k, cand,
+                       (uint32_t)cand_len, (uint32_t)seg_off, (const uint64_t *)best);
+    if (best)
+        hipLaunchKernelGGL(update_best_kernel, dim3((unsigned)nq), dim3(256), 0, st, cand, (uint32_t)cand_len, (uint32_t)seg_off, segs, k, best);
     HIP_CHECK_RET(hipGetLastError());
     *segs_out = segs;
     return LEANN_OK;
