@@ -117,7 +117,7 @@ __global__ void project_queries_kernel(const uint16_t *__restrict__ W, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // encode_kernel<CT, FUSED>: 512 threads = 8 waves; workgroup tile = 128 passages x (CT*4*32) columns
 // (CT col tiles of 32 per wave, 4 column groups, 2 row halves of 64 passages).  d <= CT*128.
-// LDS: sF[128][hp + 8] bf16 (whole K, loaded once) + 2 x sW[DP (+192)][24] bf16 (one 16-deep k-step each).
+// LDS: sF[128][hp + 8] bf16 (whole K, loaded once) + 2 x sW[DP (+192)][16] bf16 (one 16-deep k-step each, LDS-DMA).
 //   FUSED = false: E = l2norm(F W) stored as f32 (validation / leann_recompute_encode_device)
 //   FUSED = true : nothing but S[q][passage] = <f, W q> / ||W^T f|| leaves the workgroup; each wave adds
 //                  3 MFMAs per k-step (hi/lo/lo2 pieces) for one 32-query x 32-passage score tile,
@@ -130,12 +130,11 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
                                                      float *__restrict__ S, uint32_t n_rows_s) {
     constexpr int DP = CT * 128;              // padded columns of W
     constexpr int DPX = DP + (FUSED ? 192 : 0); // + three 64-query pieces of G
-    constexpr int WSTRIDE = 24;               // bf16 per column in a staged k-step (16 + 8 pad: conflict-free b128 reads)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t fstride = hp + 8; // bf16 elements per sF row
     uint16_t *sF = reinterpret_cast<uint16_t *>(smem);
-    uint16_t *sW = sF + 128 * fstride;                              // [2][DPX][WSTRIDE]
-    float *sN = reinterpret_cast<float *>(sW + 2 * DPX * WSTRIDE);  // [4 col groups][128 rows] partial sum of squares
+    uint16_t *sW = sF + 128 * fstride;                         // [2][DPX][16] linear, swizzled slots
+    float *sN = reinterpret_cast<float *>(sW + 2 * DPX * 16);  // [4 col groups][128 rows] partial sum of squares
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int rhalf = wave >> 2, cgrp = wave & 3;
@@ -156,20 +155,30 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
         }
         *reinterpret_cast<uint4 *>(sF + r * fstride + k8) = v;
     }
-    auto stage_w = [&](int buf, uint32_t ks) { // 16 k x DPX columns; W part and G part are contiguous per k-step
-        const uint4 *src = reinterpret_cast<const uint4 *>(Wp + (size_t)ks * DP * 16);
-        uint16_t *dst = sW + buf * DPX * WSTRIDE;
-        for (uint32_t idx = tid; idx < DP * 2; idx += 512) { // 2 x 16 B per column
-            const uint32_t col = idx >> 1, half = idx & 1;
-            *reinterpret_cast<uint4 *>(dst + col * WSTRIDE + half * 8) = src[idx];
+    // k-step staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave instruction, no VGPRs,
+    // asynchronous until the wave's vmcnt wait).  The LDS image is linear in 16-B slots; slot p holds global piece
+    // p ^ ((p >> 4) & 1) (swizzle on the SOURCE address), which makes the 32-B-stride fragment reads conflict-free.
+    auto stage_w = [&](int buf, uint32_t ks) {
+        const char *wsrc = reinterpret_cast<const char *>(Wp + (size_t)ks * DP * 16);
+        char *dst = reinterpret_cast<char *>(sW + buf * DPX * 16);
+        for (uint32_t i = wave; i < (uint32_t)(DP * 2 / 64); i += 8) {
+            const uint32_t p = i * 64 + lane, g = p ^ ((p >> 4) & 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (size_t)g * 16),
+                                             (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
         }
         if (FUSED) {
-            const uint4 *gs = reinterpret_cast<const uint4 *>(Gp + (size_t)ks * 192 * 16);
-            for (uint32_t idx = tid; idx < 192 * 2; idx += 512) {
-                const uint32_t col = idx >> 1, half = idx & 1;
-                *reinterpret_cast<uint4 *>(dst + (DP + col) * WSTRIDE + half * 8) = gs[idx];
+            const char *gsrc = reinterpret_cast<const char *>(Gp + (size_t)ks * 192 * 16);
+            char *gdst = dst + DP * 32;
+            for (uint32_t i = wave; i < 6; i += 8) {
+                const uint32_t p = i * 64 + lane, g = p ^ ((p >> 4) & 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)g * 16),
+                                                 (__attribute__((address_space(3))) void *)(gdst + i * 1024), 16, 0, 0);
             }
         }
+    };
+    auto frag = [&](const uint16_t *region, uint32_t col) -> bf16x8 { // 8 consecutive k of one column (16 B)
+        const uint32_t g = 2 * col + lh, p = g ^ ((g >> 4) & 1);
+        return *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(region) + p * 16);
     };
     f32x16 acc[2][CT];
     f32x16 accs; // FUSED: scores of query tile (cgrp & 1) x passage tile (2*rhalf + (cgrp >> 1))
@@ -189,14 +198,14 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
     for (uint32_t ks = 0; ks < nks; ks++) {
         const int buf = ks & 1;
         if (ks + 1 < nks) stage_w(buf ^ 1, ks + 1); // next k-step lands while this one is consumed
-        const uint16_t *w = sW + buf * DPX * WSTRIDE;
+        const uint16_t *w = sW + buf * DPX * 16;
         bf16x8 a[2], b[CT];
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
             a[rt] = *reinterpret_cast<const bf16x8 *>(sF + (rhalf * 64 + rt * 32 + l31) * fstride + ks * 16 + lh * 8);
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
-            b[ct] = *reinterpret_cast<const bf16x8 *>(w + ((cgrp * CT + ct) * 32 + l31) * WSTRIDE + lh * 8);
+            b[ct] = frag(w, (cgrp * CT + ct) * 32 + l31);
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -206,7 +215,7 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
             const bf16x8 fb = st ? a[1] : a[0]; // B operand: B[k][j = passage]  (same bytes as the A fragment of F)
 #pragma unroll
             for (int p = 0; p < 3; p++) {
-                const bf16x8 g = *reinterpret_cast<const bf16x8 *>(w + (DP + p * 64 + qt * 32 + l31) * WSTRIDE + lh * 8);
+                const bf16x8 g = frag(w + DP * 16, p * 64 + qt * 32 + l31);
                 accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, fb, accs, 0, 0, 0); // C[i = query][j = passage]
             }
         }
@@ -280,7 +289,7 @@ struct leann_recompute {
     float last_ms[3] = {0, 0, 0}; // encode, score, top-k of the last search call (HIP events)
 };
 
-static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { return 128 * (hp + 8) * 2 + 2 * (dp + (fused ? 192 : 0)) * 24 * 2 + 4 * 128 * 4; }
+static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { return 128 * (hp + 8) * 2 + 2 * (dp + (fused ? 192 : 0)) * 16 * 2 + 4 * 128 * 4; }
 
 static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st,
                          const uint16_t *Gp = nullptr, uint32_t nq = 0, float *S = nullptr) {
