@@ -200,3 +200,13 @@ def test_merge_topk_oracle(po):
     mk, md = po.merge_topk(keys, dists, counts, 8)
     allp = sorted((float(dists[s, j]), int(keys[s, j])) for s in range(S) for j in range(counts[s]))
     assert [(float(d), int(kk)) for d, kk in zip(md, mk)] == allp[:8]
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """Sanitizers run on the CPU build only (GPU ASan is unavailable on this pool)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "selfcheck"])
+    out = subprocess.run([os.path.join(root, "oracle", "selfcheck")], capture_output=True, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0 and "selfcheck OK" in out.stdout, out.stderr[-2000:]

@@ -1,0 +1,118 @@
+"""-m gpu: robustness of the C ABI: re-entrancy on one handle, large beams (64/128 KiB LDS tables),
+large k, unpadded dims, degenerate sizes, add_to_index."""
+import threading
+
+import numpy as np
+import pytest
+
+from util import recall_at_k, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_twin(po, s, X):
+    g = s.graph_export()
+    return po.Graph.from_arrays(X, g["M"], g["M0"], g["max_level"], g["entry"], g["levels"], g["upper_off"], g["adj0"], g["adjU"])
+
+
+def test_concurrent_search_on_one_handle(la, po, gpu):
+    """BackendSearcher is Send + Sync (traits.rs:11); serve.rs:289-292 calls search from many threads."""
+    X = synth(po, 20000, 128)
+    dX = la.DeviceArray.from_host(X)
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, 20000, 128, 128, 16, 64)
+    Qs = [synth(po, 300, 128, stream=1, i0=1000 * t) for t in range(8)]
+    serial = [s.search_batch(Q, 10, 64) for Q in Qs]
+    out = [None] * 8
+
+    def work(t):
+        for _ in range(5):
+            out[t] = s.search_batch(Qs[t], 10, 64)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for a, b in zip(serial, out):
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    # single-query calls interleaved with batches
+    k1, d1 = s.search(Qs[0][7], 10, 64)
+    assert (k1 == serial[0][0][7]).all()
+    s.close()
+
+
+@pytest.mark.parametrize("ef,k", [(300, 10), (700, 200), (1200, 50)])
+def test_large_beams_match_oracle(la, po, gpu, ef, k):
+    X = synth(po, 6000, 64)
+    Q = synth(po, 24, 64, stream=1)
+    G = po.Graph.build_hnsw(X, M=16, efc=64)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, 16, 32, G.max_level, G.entry, lv, uo, a0, aU)
+    ok, od, oc, _ = G.search_batch(Q, k, ef, 0, 4)
+    gk, gd, gc = s.search_batch(Q, k, ef)
+    assert (gc == oc).all() and (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    s.close()
+
+
+def test_unpadded_dims_through_build(la, po, gpu, tmp_path):
+    n, d = 3000, 130  # ld = 132 inside the library
+    X = synth(po, n, d, r=16)
+    Q = synth(po, 30, d, stream=1, r=16)
+    stem = str(tmp_path / "documents.leann")
+    la.BackendBuilder(la.BackendType.Hnsw).build(X, [], stem, d, 8, 32)
+    s = la.HnswSearcher.load(stem, d)
+    assert s.dims() == d and s.graph_info()["ld"] == 132
+    G = _oracle_twin(po, s, X)
+    ok, od, oc, _ = G.search_batch(Q, 5, 40, 0, 2)
+    gk, gd, gc = s.search_batch(Q, 5, 40)
+    assert (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    with pytest.raises(la.LeannError, match="dimensions"):
+        la.HnswSearcher.load(stem, 128)
+    s.close()
+
+
+def test_degenerate_sizes(la, po, gpu, tmp_path):
+    for n in (0, 1, 2, 3):
+        X = synth(po, max(n, 1), 32, r=0)[:n]
+        stem = str(tmp_path / f"n{n}" / "documents.leann")
+        (tmp_path / f"n{n}").mkdir()
+        la.BackendBuilder(la.BackendType.Hnsw).build(X.reshape(n, 32), [], stem, 32, 4, 8)
+        s = la.HnswSearcher.load(stem, 32)
+        assert s.len() == n and s.is_empty() == (n == 0)
+        q = synth(po, 1, 32, stream=1, r=0)[0]
+        keys, dists = s.search(q, 5, 16)
+        assert len(keys) == min(n, 5) and sorted(keys.tolist()) == list(range(min(n, 5)))
+        kb, db, cb = s.search_batch(np.zeros((0, 32), np.float32), 5, 16)
+        assert kb.shape == (0, 5)
+        s.close()
+
+
+def test_add_to_index_equals_one_shot_build(la, po, gpu, tmp_path):
+    n0, n1, d = 4000, 2500, 64
+    X = synth(po, n0 + n1, d)
+    Q = synth(po, 100, d, stream=1)
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    B = la.BackendBuilder(la.BackendType.Hnsw)
+    B.build(X[:n0], [], str(a / "documents.leann"), d, 12, 48)
+    with pytest.raises(la.LeannError, match="does not continue"):
+        B.add_to_index(X[n0:], str(a / "documents.leann"), d, n0 + 5)
+    B.add_to_index(X[n0:], str(a / "documents.leann"), d, n0)  # hnsw.rs:142-191: ids continue at start_id
+    B.build(X, [], str(b / "documents.leann"), d, 12, 48)
+    sa, sb = la.HnswSearcher.load(str(a / "documents.leann"), d), la.HnswSearcher.load(str(b / "documents.leann"), d)
+    assert sa.len() == n0 + n1
+    ka, da, _ = sa.search_batch(Q, 10, 64)
+    kb, db, _ = sb.search_batch(Q, 10, 64)
+    assert (ka == kb).all() and (da == db).all()
+    assert recall_at_k(ka, po.exact_topk(X, Q, 10)) >= 0.95
+    sa.close(); sb.close()
+
+
+def test_build_is_reproducible(la, po, gpu):
+    X = synth(po, 30000, 96)
+    dX = la.DeviceArray.from_host(X)
+    g = []
+    for _ in range(2):
+        s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, 30000, 96, 96, 16, 64)
+        g.append(s.graph_export())
+        s.close()
+    assert (np.sort(g[0]["adj0"], axis=1) == np.sort(g[1]["adj0"], axis=1)).all() and g[0]["entry"] == g[1]["entry"]
+    assert (g[0]["adjU"] == g[1]["adjU"]).all()
