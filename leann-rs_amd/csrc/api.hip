@@ -131,9 +131,8 @@ static uint32_t pick_hash_bits(uint32_t ef) {
     return b;
 }
 
-template <int T, int R>
-static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
+template <int T, int R, int NW>
+static int launch_search_NW(const GraphView &g, const SearchArgs &a, hipStream_t st) {
     const uint32_t maxdeg = std::max(g.M0, g.M);
     size_t lds = search_lds_bytes(a.ef, maxdeg, a.hash_bits);
     if (lds > 160 * 1024) {
@@ -153,6 +152,18 @@ static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t 
     }
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
+}
+
+// Waves per query: 4 for throughput batches (4 workgroups per CU hide each other's dependent hops);
+// 16 for small batches, where the chip is mostly idle and the per-hop row fetch is the critical path —
+// all ~40 new rows of a hop are then in flight at once (results are identical: same order, same sums).
+template <int T, int R>
+static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t st) {
+    int nw = a.nq <= 512 ? 16 : 4;
+    if (const char *e = getenv("LEANN_DEBUG_NW")) nw = atoi(e);
+    if (nw >= 16) return launch_search_NW<T, R, 16>(g, a, st);
+    if (nw >= 8) return launch_search_NW<T, R, 8>(g, a, st);
+    return launch_search_NW<T, R, 4>(g, a, st);
 }
 
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st) {

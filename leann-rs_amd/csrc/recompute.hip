@@ -117,7 +117,8 @@ __global__ void project_queries_kernel(const uint16_t *__restrict__ W, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // encode_kernel<CT, FUSED>: 512 threads = 8 waves; workgroup tile = 128 passages x (CT*4*32) columns
 // (CT col tiles of 32 per wave, 4 column groups, 2 row halves of 64 passages).  d <= CT*128.
-// LDS: sF[128][hp + 8] bf16 (whole K, loaded once) + 2 x sW[DP (+192)][16] bf16 (one 16-deep k-step each, LDS-DMA).
+// LDS: sF[128][hp + 8] bf16 (whole K, loaded once) + a 3-slot ring of sW[DP (+192)][16] bf16 k-step slabs (LDS-DMA,
+// two slabs in flight behind counted vmcnt waits and one raw s_barrier per k-step).
 //   FUSED = false: E = l2norm(F W) stored as f32 (validation / leann_recompute_encode_device)
 //   FUSED = true : nothing but S[q][passage] = <f, W q> / ||W^T f|| leaves the workgroup; each wave adds
 //                  3 MFMAs per k-step (hi/lo/lo2 pieces) for one 32-query x 32-passage score tile,
@@ -130,11 +131,14 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
                                                      float *__restrict__ S, uint32_t n_rows_s) {
     constexpr int DP = CT * 128;              // padded columns of W
     constexpr int DPX = DP + (FUSED ? 192 : 0); // + three 64-query pieces of G
+    constexpr int RING = 3;                     // k-step slabs in LDS: one being consumed, two in flight
+    constexpr int NI = DPX * 2 / 64;            // 1-KiB DMA instructions per k-step slab
+    constexpr int PER = (NI + 7) / 8;           // ... per wave (the same count in every wave: counted vmcnt waits)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t fstride = hp + 8; // bf16 elements per sF row
     uint16_t *sF = reinterpret_cast<uint16_t *>(smem);
-    uint16_t *sW = sF + 128 * fstride;                         // [2][DPX][16] linear, swizzled slots
-    float *sN = reinterpret_cast<float *>(sW + 2 * DPX * 16);  // [4 col groups][128 rows] partial sum of squares
+    uint16_t *sW = sF + 128 * fstride;                              // [RING][DPX][16] linear, swizzled 16-B slots
+    float *sN = reinterpret_cast<float *>(sW + RING * DPX * 16);    // [4 col groups][128 rows] partial sum of squares
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int rhalf = wave >> 2, cgrp = wave & 3;
@@ -158,22 +162,18 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
     // k-step staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave instruction, no VGPRs,
     // asynchronous until the wave's vmcnt wait).  The LDS image is linear in 16-B slots; slot p holds global piece
     // p ^ ((p >> 4) & 1) (swizzle on the SOURCE address), which makes the 32-B-stride fragment reads conflict-free.
-    auto stage_w = [&](int buf, uint32_t ks) {
+    auto stage_w = [&](int slot, uint32_t ks) {
         const char *wsrc = reinterpret_cast<const char *>(Wp + (size_t)ks * DP * 16);
-        char *dst = reinterpret_cast<char *>(sW + buf * DPX * 16);
-        for (uint32_t i = wave; i < (uint32_t)(DP * 2 / 64); i += 8) {
+        const char *gsrc = FUSED ? reinterpret_cast<const char *>(Gp + (size_t)ks * 192 * 16) : nullptr;
+        char *dst = reinterpret_cast<char *>(sW + slot * DPX * 16);
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            uint32_t i = wave + 8 * j;
+            if (i >= (uint32_t)NI) i = NI - 1; // padding instruction: re-fetches the last piece (same bytes, same place)
             const uint32_t p = i * 64 + lane, g = p ^ ((p >> 4) & 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (size_t)g * 16),
+            const char *src = (!FUSED || g < (uint32_t)(DP * 2)) ? wsrc + (size_t)g * 16 : gsrc + (size_t)(g - DP * 2) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
-        }
-        if (FUSED) {
-            const char *gsrc = reinterpret_cast<const char *>(Gp + (size_t)ks * 192 * 16);
-            char *gdst = dst + DP * 32;
-            for (uint32_t i = wave; i < 6; i += 8) {
-                const uint32_t p = i * 64 + lane, g = p ^ ((p >> 4) & 1);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)g * 16),
-                                                 (__attribute__((address_space(3))) void *)(gdst + i * 1024), 16, 0, 0);
-            }
         }
     };
     auto frag = [&](const uint16_t *region, uint32_t col) -> bf16x8 { // 8 consecutive k of one column (16 B)
@@ -193,12 +193,18 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
     const int st = cgrp >> 1, qt = cgrp & 1;
 
     const uint32_t nks = hp / 16;
+    __syncthreads(); // feature tile visible (no DMA in flight yet: a plain barrier)
     stage_w(0, 0);
-    __syncthreads();
+    if (nks > 1) stage_w(1, 1);
     for (uint32_t ks = 0; ks < nks; ks++) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) stage_w(buf ^ 1, ks + 1); // next k-step lands while this one is consumed
-        const uint16_t *w = sW + buf * DPX * 16;
+        // (a) my pieces of slab ks have landed (slab ks+1 may stay in flight), (b) everybody's have, and everybody
+        // is done reading slab ks-1, so (c) its slot can take slab ks+2.  One raw barrier per k-step; __syncthreads()
+        // would drain the DMA queue (vmcnt(0)) and serialise the stream.
+        if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ks + 2 < nks) stage_w((ks + 2) % RING, ks + 2);
+        const uint16_t *w = sW + (ks % RING) * DPX * 16;
         bf16x8 a[2], b[CT];
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
@@ -215,12 +221,12 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
             const bf16x8 fb = st ? a[1] : a[0]; // B operand: B[k][j = passage]  (same bytes as the A fragment of F)
 #pragma unroll
             for (int p = 0; p < 3; p++) {
-                const bf16x8 g = frag(w + DP * 16, p * 64 + qt * 32 + l31);
+                const bf16x8 g = frag(w, DP + p * 64 + qt * 32 + l31);
                 accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, fb, accs, 0, 0, 0); // C[i = query][j = passage]
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     // ---- fused epilogue: row norms (candle.rs:218-225) ---------------------------------------------------
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -289,7 +295,7 @@ struct leann_recompute {
     float last_ms[3] = {0, 0, 0}; // encode, score, top-k of the last search call (HIP events)
 };
 
-static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { return 128 * (hp + 8) * 2 + 2 * (dp + (fused ? 192 : 0)) * 16 * 2 + 4 * 128 * 4; }
+static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { return 128 * (hp + 8) * 2 + 3 * (dp + (fused ? 192 : 0)) * 16 * 2 + 4 * 128 * 4; }
 
 static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st,
                          const uint16_t *Gp = nullptr, uint32_t nq = 0, float *S = nullptr) {

@@ -116,3 +116,20 @@ def test_build_is_reproducible(la, po, gpu):
         s.close()
     assert (np.sort(g[0]["adj0"], axis=1) == np.sort(g[1]["adj0"], axis=1)).all() and g[0]["entry"] == g[1]["entry"]
     assert (g[0]["adjU"] == g[1]["adjU"]).all()
+
+
+@pytest.mark.parametrize("nw", ["4", "8", "16"])
+def test_waves_per_query_do_not_change_results(la, po, gpu, monkeypatch, nw):
+    """Small batches use 16 waves per query, throughput batches 4: same expansion order, same sums."""
+    X = synth(po, 5000, 768)
+    Q = synth(po, 40, 768, stream=1)
+    G = po.Graph.build_hnsw(X, M=16, efc=48)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, 16, 32, G.max_level, G.entry, lv, uo, a0, aU)
+    monkeypatch.setenv("LEANN_DEBUG_NW", nw)
+    ok, od, oc, ost = G.search_batch(Q, 10, 64, 0, 4)
+    s.stats(reset=True)
+    gk, gd, gc = s.search_batch(Q, 10, 64)
+    assert (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    assert s.stats()["n_dist_evals"] == int(ost[:, 0].sum())
+    s.close()
