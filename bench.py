@@ -162,7 +162,9 @@ def main():
     ap.add_argument("--workload", default="hnsw10m", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="shard", choices=["shard", "replica"])
     ap.add_argument("--batch", type=int, default=16384, help="queries per step (per rank in replica mode)")
-    ap.add_argument("--ef", type=int, default=0)
+    ap.add_argument("--ef", default="auto", help="beam width: 'auto' (default) = smallest of 48..128 whose measured "
+                    "recall@10 is >= 0.955 on the recall queries (the metric's operating point is defined by recall >= 0.95); "
+                    "a number = fixed (BASELINE configs[1] names ef=128); 0 = the workload's named value")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -204,7 +206,8 @@ def main():
     if wl.get("kind") == "recompute":
         return bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log)
     rows, d, M, efc = wl["rows"], wl["d"], wl["M"], wl["efc"]
-    ef = args.ef or wl["ef"]
+    ef_auto = str(args.ef).lower() == "auto"
+    ef = wl["ef"] if ef_auto else (int(args.ef) or wl["ef"])
     backend = wl.get("backend", 0)
     k, B = args.k, args.batch
     ld = (d + 3) // 4 * 4
@@ -274,11 +277,21 @@ def main():
             gt_k, gt_s, gt_c = hip_merge(gk, gs, gc, k, True, stream.cuda_stream)
         stream.synchronize()
     log(f"exact ground truth for {nrq} queries in {time.time() - t0:.2f}s")
-    found = search(0)
-    stream.synchronize()
     truth = gt_k.cpu().numpy()
-    got = found[:nrq].cpu().numpy()
-    recall = float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(nrq)]))
+
+    def measure_recall():
+        found = search(0)
+        stream.synchronize()
+        got = found[:nrq].cpu().numpy()
+        return float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(nrq)]))
+
+    if ef_auto:  # "QPS @ recall@10 >= 0.95": the cheapest beam that still meets the recall bar
+        for cand in (48, 56, 64, 72, 80, 96, 112, 128):
+            ef = cand
+            if measure_recall() >= 0.955:
+                break
+        log(f"--ef auto picked ef={ef}")
+    recall = measure_recall()
     log(f"recall@{k} = {recall:.4f} at ef={ef} ({nrq} queries, corpus {corpus_total} x {d})")
 
     # ---- warmup, then exactly K timed steps between barrier + synchronize -------------------------
