@@ -148,6 +148,12 @@ int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims, size_t ld
 typedef struct leann_recompute leann_recompute;
 int leann_recompute_create(const uint16_t *d_features, size_t n, size_t h, const uint16_t *d_weights,
                            size_t dims, int device, uint64_t key_offset, leann_recompute **out);
+/* token-level provider: features [n x L x h] bf16 + attention mask [n x L] (0 = padding, NULL = none), L in
+ * {1,2,4,8}: embedding_i = l2_normalize(masked_mean_t(W^T f_it)) — mean_pooling of candle.rs:191-216 with
+ * count.clamp(1e-9), then l2_normalize :218-225 */
+int leann_recompute_create_pooled(const uint16_t *d_features, const uint8_t *d_mask, size_t n,
+                                  size_t tokens_per_passage, size_t h, const uint16_t *d_weights,
+                                  size_t dims, int device, uint64_t key_offset, leann_recompute **out);
 int leann_recompute_search_batch_device(const leann_recompute *r, const float *d_queries, size_t nq,
                                         size_t top_k, const uint8_t *d_allow_mask, uint64_t *d_keys,
                                         float *d_scores, uint32_t *d_counts, void *stream);

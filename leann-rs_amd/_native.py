@@ -57,6 +57,8 @@ SIGNATURES = {
     "leann_scan_topk_device": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                         vp, C.c_uint64, vp, vp, vp, vp]),
     "leann_recompute_create": (C.c_int, [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "leann_recompute_create_pooled": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_uint64,
+                                               C.POINTER(vp)]),
     "leann_recompute_search_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp]),
     "leann_recompute_encode_device": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
     "leann_recompute_len": (C.c_size_t, [vp]),

@@ -124,11 +124,12 @@ __global__ void project_queries_kernel(const uint16_t *__restrict__ W, uint32_t 
 //                  3 MFMAs per k-step (hi/lo/lo2 pieces) for one 32-query x 32-passage score tile,
 //                  reusing the feature fragment it already holds as the B operand.
 // ------------------------------------------------------------------------------------------------
-template <int CT, bool FUSED>
+template <int CT, bool FUSED, bool POOL>
 __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict__ F, uint64_t n, uint32_t h, uint32_t hp,
                                                      const uint16_t *__restrict__ Wp, uint32_t d, uint32_t ld_out,
                                                      float *__restrict__ E, const uint16_t *__restrict__ Gp, uint32_t nq,
-                                                     float *__restrict__ S, uint32_t n_rows_s) {
+                                                     float *__restrict__ S, uint32_t n_rows_s, uint32_t L,
+                                                     const uint8_t *__restrict__ mask) {
     constexpr int DP = CT * 128;              // padded columns of W
     constexpr int DPX = DP + (FUSED ? 192 : 0); // + three 64-query pieces of G
     constexpr int RING = 3;                     // k-step slabs in LDS: one being consumed, two in flight
@@ -139,6 +140,8 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
     uint16_t *sF = reinterpret_cast<uint16_t *>(smem);
     uint16_t *sW = sF + 128 * fstride;                              // [RING][DPX][16] linear, swizzled 16-B slots
     float *sN = reinterpret_cast<float *>(sW + RING * DPX * 16);    // [4 col groups][128 rows] partial sum of squares
+    float *sM = sN + 4 * 128;                                       // [128] attention mask of the tile's token rows (0/1)
+    float *sC = sM + 128;                                           // [128] max(token count, 1e-9) at each passage's first row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int rhalf = wave >> 2, cgrp = wave & 3;
@@ -192,8 +195,17 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
             for (int i = 0; i < 16; i++) acc[rt][ct][i] = 0.f;
     const int st = cgrp >> 1, qt = cgrp & 1;
 
+    if (POOL && tid < 128) {
+        const uint64_t row = row_base + tid;
+        sM[tid] = (row < n && (!mask || mask[row] != 0)) ? 1.f : 0.f;
+    }
     const uint32_t nks = hp / 16;
-    __syncthreads(); // feature tile visible (no DMA in flight yet: a plain barrier)
+    __syncthreads(); // feature tile + mask visible (no DMA in flight yet: a plain barrier)
+    if (POOL && tid < 128 && (tid % L) == 0) {
+        float c = 0.f;
+        for (uint32_t j = 0; j < L; j++) c += sM[tid + j];
+        sC[tid] = c < 1e-9f ? 1e-9f : c; // candle.rs:213 count.clamp(1e-9, inf)
+    }
     stage_w(0, 0);
     if (nks > 1) stage_w(1, 1);
     for (uint32_t ks = 0; ks < nks; ks++) {
@@ -228,8 +240,38 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
     }
     __syncthreads();
 
-    // ---- fused epilogue: row norms (candle.rs:218-225) ---------------------------------------------------
-    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // ---- masked mean pooling over the L token rows of a passage (candle.rs:191-216) ------------------------
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): the four registers of a
+    // group are four consecutive token rows, so L <= 4 pools in registers and L = 8 adds the lane + 32 partner.
+    // The pooled mean lands in the register of the passage's first token; the other registers become 0.
+    if (POOL) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const int r0 = rhalf * 64 + rt * 32 + 8 * g4 + 4 * lh;
+            const float m0 = sM[r0], m1 = sM[r0 + 1], m2 = sM[r0 + 2], m3 = sM[r0 + 3];
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                float v0 = acc[rt][ct][4 * g4] * m0, v1 = acc[rt][ct][4 * g4 + 1] * m1;
+                float v2 = acc[rt][ct][4 * g4 + 2] * m2, v3 = acc[rt][ct][4 * g4 + 3] * m3;
+                if (L == 1) {
+                    v0 /= sC[r0]; v1 /= sC[r0 + 1]; v2 /= sC[r0 + 2]; v3 /= sC[r0 + 3];
+                } else if (L == 2) {
+                    v0 = (v0 + v1) / sC[r0]; v2 = (v2 + v3) / sC[r0 + 2]; v1 = 0.f; v3 = 0.f;
+                } else if (L == 4) {
+                    v0 = (((v0 + v1) + v2) + v3) / sC[r0]; v1 = v2 = v3 = 0.f;
+                } else { // L == 8: tokens 0-3 in the lane with lh = 0, tokens 4-7 in its lh = 1 partner
+                    float a = ((v0 + v1) + v2) + v3;
+                    float t = a + __shfl_xor(a, 32, 64);
+                    v0 = lh == 0 ? t / sC[r0] : 0.f; v1 = v2 = v3 = 0.f;
+                }
+                acc[rt][ct][4 * g4] = v0; acc[rt][ct][4 * g4 + 1] = v1; acc[rt][ct][4 * g4 + 2] = v2; acc[rt][ct][4 * g4 + 3] = v3;
+            }
+        }
+    }
+    } // POOL
+    // ---- row norms of the pooled embeddings (candle.rs:218-225) ---------------------------------------------
 #pragma unroll
     for (int rt = 0; rt < 2; rt++) {
 #pragma unroll
@@ -248,18 +290,34 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
     }
     __syncthreads();
     if (FUSED) {
-        // score tile: rows (regs) = queries, col (lane & 31) = passage -> 128-B coalesced stores into S[q][passage]
+        // score tile: rows (regs) = queries, col (lane & 31) = token row.  Mask, pool the L adjacent lanes of a
+        // passage, then <mean, q> / ||mean||; 128-B coalesced stores into S[q][passage] when L = 1.
         const int r = rhalf * 64 + st * 32 + l31;
         const uint64_t row = row_base + r;
         const float ss = ((sN[r] + sN[128 + r]) + (sN[256 + r] + sN[384 + r]));
         float nrm = sqrtf(ss);
         nrm = nrm < 1e-12f ? 1e-12f : nrm;
-        if (row < n) {
+        if (!POOL) {
+            if (row < n) {
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const uint32_t q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                if (q < nq) S[(size_t)q * n_rows_s + row] = accs[reg] / nrm;
+                for (int reg = 0; reg < 16; reg++) {
+                    const uint32_t q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    if (q < nq) S[(size_t)q * n_rows_s + row] = accs[reg] / nrm;
+                }
             }
+            return;
+        }
+        const float m = sM[r];
+        const bool first = (r % L) == 0;
+        const float cnt = first ? sC[r] : 1.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            float v = accs[reg] * m;
+            if (L >= 2) v += __shfl_xor(v, 1, 64);
+            if (L >= 4) v += __shfl_xor(v, 2, 64);
+            if (L >= 8) v += __shfl_xor(v, 4, 64);
+            const uint32_t q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (first && row < n && q < nq) S[(size_t)q * n_rows_s + row / L] = (v / cnt) / nrm;
         }
         return;
     }
@@ -272,11 +330,11 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
             const float ss = ((sN[r] + sN[128 + r]) + (sN[256 + r] + sN[384 + r])); // fixed order: reproducible
             float nrm = sqrtf(ss);
             nrm = nrm < 1e-12f ? 1e-12f : nrm;
-            if (row < n) {
+            if (row < n && (r % L) == 0) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
                     const uint32_t col = (cgrp * CT + ct) * 32 + l31;
-                    if (col < ld_out) E[(size_t)row * ld_out + col] = col < d ? acc[rt][ct][reg] / nrm : 0.f;
+                    if (col < ld_out) E[(size_t)(row / L) * ld_out + col] = col < d ? acc[rt][ct][reg] / nrm : 0.f;
                 }
             }
         }
@@ -292,30 +350,36 @@ struct leann_recompute {
     size_t n = 0, h = 0, hp = 0, d = 0, dp = 0, ld = 0;
     uint64_t key_offset = 0;
     int ct = 0;
+    uint32_t L = 1;                 // token rows per passage (masked mean pooling), 1 | 2 | 4 | 8
+    const uint8_t *mask = nullptr;  // borrowed [n x L] attention mask or null (all ones)
     float last_ms[3] = {0, 0, 0}; // encode, score, top-k of the last search call (HIP events)
 };
 
-static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { return 128 * (hp + 8) * 2 + 3 * (dp + (fused ? 192 : 0)) * 16 * 2 + 4 * 128 * 4; }
+static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { return 128 * (hp + 8) * 2 + 3 * (dp + (fused ? 192 : 0)) * 16 * 2 + 6 * 128 * 4; }
 
 static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st,
                          const uint16_t *Gp = nullptr, uint32_t nq = 0, float *S = nullptr) {
     const bool fused = Gp != nullptr;
     const size_t lds = encode_lds_bytes(r->hp, r->dp, fused);
-    const unsigned grid = (unsigned)((rows + 127) / 128);
-    const uint16_t *F = r->F + row0 * r->h;
+    // row0 / rows count PASSAGES; the kernel works on token rows (L per passage, tiles of 128 token rows)
+    const uint64_t tok0 = row0 * r->L, toks = rows * r->L;
+    const unsigned grid = (unsigned)((toks + 127) / 128);
+    const uint16_t *F = r->F + tok0 * r->h;
+    const uint8_t *mk = r->mask ? r->mask + tok0 : nullptr;
+#define LAUNCH_ONE(CT, FU, PO)                                                                                            \
+    do {                                                                                                                  \
+        HIP_CHECK_RET(hipFuncSetAttribute((const void *)encode_kernel<CT, FU, PO>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                          160 * 1024));                                                                   \
+        hipLaunchKernelGGL((encode_kernel<CT, FU, PO>), dim3(grid), dim3(512), lds, st, F, (uint64_t)toks, (uint32_t)r->h,        \
+                           (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E, Gp, nq, S, (uint32_t)rows, r->L, mk);      \
+    } while (0)
 #define LAUNCH_CT(CT)                                                                                                     \
     do {                                                                                                                  \
-        if (fused) {                                                                                                      \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void *)encode_kernel<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                              160 * 1024));                                                               \
-            hipLaunchKernelGGL((encode_kernel<CT, true>), dim3(grid), dim3(512), lds, st, F, (uint64_t)rows, (uint32_t)r->h,     \
-                               (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E, Gp, nq, S, (uint32_t)rows);     \
-        } else {                                                                                                          \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void *)encode_kernel<CT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                              160 * 1024));                                                               \
-            hipLaunchKernelGGL((encode_kernel<CT, false>), dim3(grid), dim3(512), lds, st, F, (uint64_t)rows, (uint32_t)r->h,    \
-                               (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E, Gp, nq, S, (uint32_t)rows);     \
-        }                                                                                                                 \
+        const bool pool = r->L > 1 || r->mask != nullptr;                                                                 \
+        if (fused && pool) LAUNCH_ONE(CT, true, true);                                                                    \
+        else if (fused) LAUNCH_ONE(CT, true, false);                                                                      \
+        else if (pool) LAUNCH_ONE(CT, false, true);                                                                       \
+        else LAUNCH_ONE(CT, false, false);                                                                                \
     } while (0)
     switch (r->ct) {
         case 1: LAUNCH_CT(1); break;
@@ -326,6 +390,7 @@ static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows,
         default: leann_set_error("recompute: unsupported dims %zu", r->d); return LEANN_ERR_INVALID;
     }
 #undef LAUNCH_CT
+#undef LAUNCH_ONE
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
 }
@@ -370,6 +435,21 @@ extern "C" int leann_recompute_create(const uint16_t *d_features, size_t n, size
     HIP_CHECK_RET(hipGetLastError());
     HIP_CHECK_RET(hipDeviceSynchronize());
     *out = r;
+    return LEANN_OK;
+}
+// Token-level provider: features [n x L x h], attention mask [n x L] (0 = padding) -> masked mean pooling
+// (candle.rs:191-216) between the dense layer and the normalisation.
+extern "C" int leann_recompute_create_pooled(const uint16_t *d_features, const uint8_t *d_mask, size_t n, size_t tokens_per_passage,
+                                             size_t h, const uint16_t *d_weights, size_t dims, int device, uint64_t key_offset,
+                                             leann_recompute **out) {
+    if (tokens_per_passage != 1 && tokens_per_passage != 2 && tokens_per_passage != 4 && tokens_per_passage != 8) {
+        leann_set_error("leann_recompute_create_pooled: tokens_per_passage must be 1, 2, 4 or 8 (got %zu)", tokens_per_passage);
+        return LEANN_ERR_INVALID;
+    }
+    int rc = leann_recompute_create(d_features, n, h, d_weights, dims, device, key_offset, out);
+    if (rc) return rc;
+    (*out)->L = (uint32_t)tokens_per_passage;
+    (*out)->mask = d_mask;
     return LEANN_OK;
 }
 extern "C" void leann_recompute_close(leann_recompute *r) {

@@ -266,6 +266,34 @@ void orc_recompute_encode(const uint16_t *F, uint64_t n, uint32_t h, const uint1
     }
 }
 
+/* Token-level provider: dense per token, masked mean over the L tokens of a passage
+ * (candle.rs:191-216: sum(output * mask) / clamp(sum(mask), 1e-9)), then l2_normalize (:218-225). */
+void orc_recompute_encode_pooled(const uint16_t *F, const uint8_t *mask, uint64_t n, uint32_t L, uint32_t h,
+                                 const uint16_t *W, uint32_t d, float *out) {
+    float *e = (float *)malloc((size_t)d * sizeof(float));
+    for (uint64_t i = 0; i < n; i++) {
+        float *x = out + i * d;
+        float cnt = 0.0f;
+        for (uint32_t j = 0; j < d; j++) x[j] = 0.0f;
+        for (uint32_t t = 0; t < L; t++) {
+            const uint16_t *f = F + (i * L + t) * h;
+            float m = (!mask || mask[i * L + t]) ? 1.0f : 0.0f;
+            for (uint32_t j = 0; j < d; j++) e[j] = 0.0f;
+            for (uint32_t k = 0; k < h; k++) {
+                float fk = bf16_f32(f[k]);
+                const uint16_t *wk = W + (size_t)k * d;
+                for (uint32_t j = 0; j < d; j++) e[j] = fmaf(bf16_f32(wk[j]), fk, e[j]);
+            }
+            for (uint32_t j = 0; j < d; j++) x[j] = x[j] + e[j] * m;
+            cnt = cnt + m;
+        }
+        if (cnt < 1e-9f) cnt = 1e-9f;
+        for (uint32_t j = 0; j < d; j++) x[j] = x[j] / cnt;
+        orc_l2_normalize(x, d);
+    }
+    free(e);
+}
+
 /* ============================================================================================
  * Graph index
  * ========================================================================================== */

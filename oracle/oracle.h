@@ -108,6 +108,8 @@ void orc_synth_features(uint64_t seed, uint32_t h, uint32_t n_clusters, float si
                         uint64_t i0, uint64_t n, uint16_t *out);
 void orc_synth_weights(uint64_t seed, uint32_t h, uint32_t d, uint16_t *out);
 void orc_recompute_encode(const uint16_t *F, uint64_t n, uint32_t h, const uint16_t *W, uint32_t d, float *out);
+void orc_recompute_encode_pooled(const uint16_t *F, const uint8_t *mask, uint64_t n, uint32_t L, uint32_t h,
+                                 const uint16_t *W, uint32_t d, float *out);
 
 /* ---- pooling / normalise glue (src/embedding/candle.rs:191-225) ---------------------------- */
 void orc_l2_normalize(float *x, uint32_t d); /* x / max(sqrt(sum x^2), 1e-12), sequential sum */

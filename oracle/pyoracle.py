@@ -73,6 +73,7 @@ def lib():
                                          C.c_uint64, u16p]
         L.orc_synth_weights.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, u16p]
         L.orc_recompute_encode.argtypes = [u16p, C.c_uint64, C.c_uint32, u16p, C.c_uint32, f32p]
+        L.orc_recompute_encode_pooled.argtypes = [u16p, u8p, C.c_uint64, C.c_uint32, C.c_uint32, u16p, C.c_uint32, f32p]
         _LIB = L
     return _LIB
 
@@ -202,6 +203,19 @@ def recompute_encode(F, W):
     u16p = C.POINTER(C.c_uint16)
     lib().orc_recompute_encode(F.ctypes.data_as(u16p), F.shape[0], F.shape[1], W.ctypes.data_as(u16p), W.shape[1],
                                _p(out, f32p))
+    return out
+
+
+def recompute_encode_pooled(F, mask, W, L):
+    """F: [n*L, h] token features, mask: [n, L] or None"""
+    F = np.ascontiguousarray(F, np.uint16)
+    W = np.ascontiguousarray(W, np.uint16)
+    n = F.shape[0] // L
+    out = np.empty((n, W.shape[1]), np.float32)
+    u16p = C.POINTER(C.c_uint16)
+    m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+    lib().orc_recompute_encode_pooled(F.ctypes.data_as(u16p), _p(m, u8p), n, L, F.shape[1], W.ctypes.data_as(u16p),
+                                      W.shape[1], _p(out, f32p))
     return out
 
 

@@ -83,3 +83,37 @@ def test_recompute_allow_mask_and_offset(la, po, gpu):
         k0, s0 = po.scan_topk(E, Q[i], k, mode=0, allow_mask=mask)
         assert np.abs(ds.to_host()[i] - s0).max() <= 1e-5
     L.leann_recompute_close(r)
+
+
+@pytest.mark.parametrize("L", [1, 2, 4, 8])
+def test_masked_mean_pooling_provider(la, po, gpu, L):
+    """Token-level provider: dense per token -> masked mean over L tokens (candle.rs:191-216, count clamp 1e-9)
+    -> l2_normalize; search scores against the oracle's literal order."""
+    n, h, d, nq, k = 1500, 128, 384, 20, 10
+    Lc, chk = la.lib(), la._native.check
+    F = po.synth_features(SEED, h, 64, 1.0, 0, 0, n * L)          # token rows
+    W = po.synth_weights(SEED, h, d)
+    rng = np.random.default_rng(L)
+    mask = (rng.random((n, L)) < 0.7).astype(np.uint8)
+    mask[:5] = 0                                                   # fully padded passages: count clamps to 1e-9 -> zero vector
+    mask[5:10] = 1
+    E = po.recompute_encode_pooled(F, mask, W, L)
+    assert np.abs(E[:5]).max() == 0.0
+    Q = po.recompute_encode(po.synth_features(SEED, h, 64, 1.0, 1, 0, nq), W)
+    dF, dW, dM = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W), la.DeviceArray.from_host(mask)
+    r = C.c_void_p()
+    chk(Lc.leann_recompute_create_pooled(dF.ptr, dM.ptr, n, L, h, dW.ptr, d, 0, 0, C.byref(r)))
+    dE = la.DeviceArray((n, d), np.float32)
+    chk(Lc.leann_recompute_encode_device(r, 0, n, dE.ptr, None))
+    la.sync()
+    assert np.abs(dE.to_host() - E).max() <= 2e-6
+    dQ = la.DeviceArray.from_host(Q)
+    dk, ds, dc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    chk(Lc.leann_recompute_search_batch_device(r, dQ.ptr, nq, k, None, dk.ptr, ds.ptr, dc.ptr, None))
+    la.sync()
+    gk, gs = dk.to_host(), ds.to_host()
+    for i in range(nq):
+        k0, s0 = po.scan_topk(E, Q[i], k, mode=0)
+        assert np.abs(gs[i] - s0).max() <= 1e-5
+        assert len(set(gk[i].tolist()) & set(k0.tolist())) >= k - 1
+    Lc.leann_recompute_close(r)
