@@ -330,6 +330,13 @@ static inline const uint32_t *nbrs(const orc_graph *g, uint32_t node, uint32_t l
     *cap = g->M;
     return g->adjU + ((size_t)g->upper_off[node] + (level - 1)) * g->M;
 }
+static inline void prefetch_row(const orc_graph *g, uint32_t id) {
+    const char *p = (const char *)(g->X + (size_t)id * g->ld);
+    __builtin_prefetch(p, 0, 0);
+    __builtin_prefetch(p + 64, 0, 0);
+    __builtin_prefetch(p + 128, 0, 0);
+    __builtin_prefetch(p + 192, 0, 0);
+}
 static inline float gdist(const orc_graph *g, const float *q, uint32_t id) {
     if (g_fast_dot) return 1.0f - orc_dot_fast(q, g->X + (size_t)id * g->ld, g->d);
     return 1.0f - orc_dot_canon(q, g->X + (size_t)id * g->ld, g->d);
@@ -460,6 +467,7 @@ static void search_layer_heap(const orc_graph *g, const float *q, const uint64_t
         for (uint32_t t = 0; t < cap; t++) {
             uint32_t e = nb[t];
             if (e == ORC_EMPTY) continue;
+            if (t + 1 < cap && nb[t + 1] != ORC_EMPTY) prefetch_row(g, nb[t + 1]); /* as CPU HNSW libraries do */
             if (c->stamp[e] == c->epoch) continue;
             c->stamp[e] = c->epoch;
             uint64_t k = mk_key(gdist(g, q, e), e);
@@ -506,6 +514,7 @@ static void search_layer_list(const orc_graph *g, const float *q, const uint64_t
         for (uint32_t t = 0; t < cap; t++) {
             uint32_t e = nb[t];
             if (e == ORC_EMPTY) continue;
+            if (t + 1 < cap && nb[t + 1] != ORC_EMPTY) prefetch_row(g, nb[t + 1]);
             if (c->stamp[e] == c->epoch) continue;
             c->stamp[e] = c->epoch;
             uint64_t k = mk_key(gdist(g, q, e), e);
