@@ -331,7 +331,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))  # measured with rocprofv3 --pmc on this exact command (profiles/*.md); only valid for the same beam
+            traffic = tj.get("hbm_bytes_per_launch") if tj.get("ef_search") == ef and B == 16384 and k == 10 else None
         except Exception:
             traffic = None
 
@@ -361,7 +362,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "beam_search_kernel<3,4,4>" if ld <= 768 else "beam_search_kernel",
+            "traffic": traffic, "kernel": "beam_search_kernel<3,4,4,false>" if ld == 768 else "beam_search_kernel",
             "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_query": bytes_per_query,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "dist_evals_per_query": evals / nq_stat, "hops_per_query": (hops0 + hopsU) / nq_stat,
