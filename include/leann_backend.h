@@ -61,6 +61,12 @@ int leann_backend_search_batch(const leann_backend *h, const float *queries, siz
                                size_t top_k, size_t complexity, uint64_t *keys, float *dists,
                                uint32_t *counts);
 
+/* Additive: request coalescing for servers that call leann_backend_search from many threads (one query per
+ * call, src/cli/serve.rs:289-292).  Concurrent callers are gathered for up to wait_us microseconds (or
+ * max_batch queries) and answered by one batched launch; results are identical.  (0, 0) disables. */
+int leann_backend_set_coalescing(leann_backend *h, uint32_t wait_us, uint32_t max_batch);
+int leann_backend_coalescing_stats(const leann_backend *h, uint64_t *n_launches, uint64_t *n_queries);
+
 /* BackendSearcher::len  src/backend/traits.rs:24 */
 size_t leann_backend_len(const leann_backend *h);
 size_t leann_backend_dims(const leann_backend *h);

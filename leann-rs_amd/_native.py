@@ -35,6 +35,8 @@ SIGNATURES = {
     "leann_backend_open": (C.c_int, [C.c_char_p, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(vp)]),
     "leann_backend_search": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, u64p, f32p, C.POINTER(C.c_size_t)]),
     "leann_backend_search_batch": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p, u32p]),
+    "leann_backend_set_coalescing": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+    "leann_backend_coalescing_stats": (C.c_int, [vp, u64p, u64p]),
     "leann_backend_len": (C.c_size_t, [vp]),
     "leann_backend_dims": (C.c_size_t, [vp]),
     "leann_backend_close": (None, [vp]),

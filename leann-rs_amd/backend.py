@@ -106,6 +106,15 @@ class BackendSearcher:
         N.check(N.lib().leann_backend_search_batch_device(self._h, d_queries, nq, top_k, complexity,
                                                           d_keys, d_dists, d_counts, d_stats, stream))
 
+    def set_coalescing(self, wait_us=200, max_batch=4096):
+        """gather concurrent single-query search() callers into one batched launch ((0, 0) disables)"""
+        N.check(N.lib().leann_backend_set_coalescing(self._h, wait_us, max_batch))
+
+    def coalescing_stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        N.check(N.lib().leann_backend_coalescing_stats(self._h, C.byref(a), C.byref(b)))
+        return {"launches": a.value, "queries": b.value}
+
     def len(self):
         return int(N.lib().leann_backend_len(self._h))
 

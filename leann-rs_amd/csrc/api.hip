@@ -15,6 +15,9 @@
 #include <string>
 #include <vector>
 #include <sys/stat.h>
+#include <chrono>
+#include <condition_variable>
+#include <thread>
 
 static thread_local char g_err[2048] = "";
 extern "C" void leann_set_error(const char *fmt, ...) {
@@ -57,6 +60,7 @@ extern "C" int leann_device_sync(int device) {
     return LEANN_OK;
 }
 
+extern "C" int leann_backend_set_coalescing(leann_backend *h, uint32_t wait_us, uint32_t max_batch);
 // ---- handle (structs in internal.h) ---------------------------------------------------------------
 static void ws_free(Workspace *w) {
     if (!w) return;
@@ -96,6 +100,7 @@ void leann_internal_free_graph(leann_backend *h) {
 
 extern "C" void leann_backend_close(leann_backend *h) {
     if (!h) return;
+    leann_backend_set_coalescing(h, 0, 0); // stops the dispatcher thread, if any
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (auto *w : h->free_ws) ws_free(w);
@@ -307,9 +312,117 @@ extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *
     return LEANN_OK;
 }
 
-extern "C" int leann_backend_search(const leann_backend *h, const float *query, size_t top_k, size_t complexity,
+// ---- request coalescing --------------------------------------------------------------
+// The reference serves one query per call from many threads (cli/serve.rs:289-292).  One query is one
+// workgroup: ~1 ms of latency and 1/1000 of the chip.  With coalescing enabled on a handle, concurrent
+// leann_backend_search callers are gathered for up to `wait_us` (or `max_batch` queries) and answered by ONE
+// batched launch, transparently to the callers — the Rust server needs no change.
+struct PendingQuery {
+    const float *q;
+    size_t k, ef;
+    uint64_t *keys;
+    float *dists;
+    size_t *n_out;
+    int rc = 0;
+    bool done = false;
+    std::string err;
+};
+struct Coalescer {
+    leann_backend *h = nullptr;
+    uint32_t wait_us = 200, max_batch = 4096;
+    std::mutex mu;
+    std::condition_variable cv_submit, cv_done;
+    std::vector<PendingQuery *> queue;
+    std::thread th;
+    bool stop = false;
+    uint64_t n_launches = 0, n_queries = 0;
+
+    void run() {
+        (void)hipSetDevice(h->device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_submit.wait(lk, [&] { return stop || !queue.empty(); });
+            if (stop && queue.empty()) return;
+            auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
+            cv_submit.wait_until(lk, deadline, [&] { return stop || queue.size() >= max_batch; });
+            std::vector<PendingQuery *> batch;
+            batch.swap(queue);
+            lk.unlock();
+            // one launch per distinct (top_k, complexity)
+            std::map<std::pair<size_t, size_t>, std::vector<PendingQuery *>> groups;
+            for (auto *p : batch) groups[{p->k, p->ef}].push_back(p);
+            const size_t d = h->g.d;
+            for (auto &kv : groups) {
+                auto &g = kv.second;
+                const size_t nq = g.size(), k = kv.first.first;
+                std::vector<float> Q(nq * d);
+                for (size_t i = 0; i < nq; i++) memcpy(Q.data() + i * d, g[i]->q, d * 4);
+                std::vector<uint64_t> keys(nq * std::max<size_t>(k, 1));
+                std::vector<float> dists(nq * std::max<size_t>(k, 1));
+                std::vector<uint32_t> counts(nq);
+                int rc = leann_backend_search_batch(h, Q.data(), nq, k, kv.first.second, keys.data(), dists.data(), counts.data());
+                std::string err = rc ? leann_last_error() : "";
+                for (size_t i = 0; i < nq; i++) {
+                    if (!rc) {
+                        memcpy(g[i]->keys, keys.data() + i * k, counts[i] * 8);
+                        memcpy(g[i]->dists, dists.data() + i * k, counts[i] * 4);
+                        *g[i]->n_out = counts[i];
+                    }
+                    g[i]->rc = rc;
+                    g[i]->err = err;
+                }
+                n_launches++;
+                n_queries += nq;
+            }
+            lk.lock();
+            for (auto *p : batch) p->done = true;
+            cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" int leann_backend_set_coalescing(leann_backend *h, uint32_t wait_us, uint32_t max_batch) {
+    if (!h) { leann_set_error("leann_backend_set_coalescing: null handle"); return LEANN_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->coalescer) { // reconfigure or disable
+        Coalescer *c = h->coalescer;
+        { std::lock_guard<std::mutex> l2(c->mu); c->stop = true; }
+        c->cv_submit.notify_all();
+        c->th.join();
+        delete c;
+        h->coalescer = nullptr;
+    }
+    if (wait_us == 0 && max_batch == 0) return LEANN_OK;
+    Coalescer *c = new Coalescer();
+    c->h = h;
+    c->wait_us = wait_us;
+    c->max_batch = max_batch ? max_batch : 4096;
+    c->th = std::thread([c] { c->run(); });
+    h->coalescer = c;
+    return LEANN_OK;
+}
+extern "C" int leann_backend_coalescing_stats(const leann_backend *h, uint64_t *n_launches, uint64_t *n_queries) {
+    if (!h || !h->coalescer) { leann_set_error("coalescing is not enabled on this handle"); return LEANN_ERR_INVALID; }
+    std::lock_guard<std::mutex> l2(h->coalescer->mu);
+    if (n_launches) *n_launches = h->coalescer->n_launches;
+    if (n_queries) *n_queries = h->coalescer->n_queries;
+    return LEANN_OK;
+}
+
+extern "C" int leann_backend_search(const leann_backend *hc, const float *query, size_t top_k, size_t complexity,
                                     uint64_t *keys, float *dists, size_t *n_out) {
     if (!n_out) { leann_set_error("leann_backend_search: n_out is null"); return LEANN_ERR_INVALID; }
+    leann_backend *h = const_cast<leann_backend *>(hc);
+    if (h && h->coalescer && query && keys && dists && top_k > 0 && h->g.n > 0) {
+        Coalescer *c = h->coalescer;
+        PendingQuery p{query, top_k, complexity, keys, dists, n_out};
+        std::unique_lock<std::mutex> lk(c->mu);
+        c->queue.push_back(&p);
+        c->cv_submit.notify_one();
+        c->cv_done.wait(lk, [&] { return p.done; });
+        if (p.rc) leann_set_error("%s", p.err.c_str());
+        return p.rc;
+    }
     uint32_t cnt = 0;
     int rc = leann_backend_search_batch(h, query, 1, top_k, complexity, keys, dists, &cnt);
     *n_out = cnt;

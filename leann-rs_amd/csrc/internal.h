@@ -16,6 +16,7 @@ struct Workspace { // staging of the host-pointer API; one per concurrent caller
     hipStream_t stream = nullptr;
 };
 
+struct Coalescer;
 struct leann_backend {
     int kind = LEANN_BACKEND_HNSW, device = 0;
     GraphView g{};
@@ -31,6 +32,7 @@ struct leann_backend {
     unsigned long long *gpool = nullptr;
     uint32_t *gpool_lock = nullptr, *gpool_ctr = nullptr;
     leann_search_stats stats{};
+    Coalescer *coalescer = nullptr; // optional request coalescing for single-query callers (api.hip)
 };
 
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st);

@@ -187,17 +187,21 @@ __global__ void finalize_scan_kernel(const uint64_t *__restrict__ keys, uint32_t
     }
 }
 
+__global__ void update_best_kernel(const uint64_t *__restrict__ cand, uint32_t cand_stride_q, uint32_t seg_off, uint32_t n_segs,
+                                   uint32_t k, uint64_t *__restrict__ best);
 // one chunk: scores of rows [0, rows) of Xbase against all queries, per-segment top-k appended to cand
 int leann_internal_scan_chunk(const float *Xbase, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, uint32_t k,
                               const uint8_t *allow, uint64_t pos0, float *S, uint64_t *cand, size_t cand_len, size_t seg_off,
-                              hipStream_t st, size_t *segs_out, hipEvent_t mid = nullptr) {
+                              hipStream_t st, size_t *segs_out, hipEvent_t mid = nullptr, uint64_t *best = nullptr) {
     dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
     hipLaunchKernelGGL(score_mfma_kernel, g1, dim3(256), 0, st, Xbase, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld, d_queries,
                        (uint32_t)nq, (uint32_t)dims, (uint64_t)0, (uint32_t)rows, S);
     if (mid) (void)hipEventRecord(mid, st);
     unsigned segs = (unsigned)((rows + SEG - 1) / SEG);
     hipLaunchKernelGGL(topk_scores_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, S, (uint32_t)rows, pos0, allow, k, cand,
-                       (uint32_t)cand_len, (uint32_t)seg_off);
+                       (uint32_t)cand_len, (uint32_t)seg_off, (const uint64_t *)best);
+    if (best)
+        hipLaunchKernelGGL(update_best_kernel, dim3((unsigned)nq), dim3(256), 0, st, cand, (uint32_t)cand_len, (uint32_t)seg_off, segs, k, best);
     HIP_CHECK_RET(hipGetLastError());
     *segs_out = segs;
     return LEANN_OK;
@@ -271,18 +275,20 @@ extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims
     for (size_t c = 0; c < n_chunks; c++) total_segs += (std::min(chunk, n - c * chunk) + SEG - 1) / SEG;
     if (total_segs == 0) total_segs = 1;
     float *S = nullptr;
-    uint64_t *candA = nullptr, *candB = nullptr;
+    uint64_t *candA = nullptr, *candB = nullptr, *best = nullptr;
     size_t cand_len = std::max<size_t>(total_segs * k, k); // per query
     HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * nq * std::max<size_t>(chunk, 1)));
     HIP_CHECK_RET(hipMalloc((void **)&candA, sizeof(uint64_t) * nq * cand_len));
     HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
+    HIP_CHECK_RET(hipMalloc((void **)&best, sizeof(uint64_t) * nq * k));
     HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
+    HIP_CHECK_RET(hipMemsetAsync(best, 0xFF, sizeof(uint64_t) * nq * k, st));
     size_t seg_off = 0;
     int rc = LEANN_OK;
     for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
         size_t row0 = c * chunk, rows = std::min(chunk, n - row0), segs = 0;
         rc = leann_internal_scan_chunk(d_rows + row0 * ld, rows, dims, ld, d_queries, nq, k, d_allow_mask, row0, S, candA, cand_len,
-                                       seg_off, st, &segs);
+                                       seg_off, st, &segs, nullptr, n_chunks > 1 ? best : nullptr);
         seg_off += segs;
     }
     if (rc == LEANN_OK)
@@ -293,6 +299,7 @@ extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims
     (void)hipFree(S);
     (void)hipFree(candA);
     (void)hipFree(candB);
+    (void)hipFree(best);
     return rc;
 }
 

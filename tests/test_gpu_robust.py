@@ -133,3 +133,51 @@ def test_waves_per_query_do_not_change_results(la, po, gpu, monkeypatch, nw):
     assert (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
     assert s.stats()["n_dist_evals"] == int(ost[:, 0].sum())
     s.close()
+
+
+def test_request_coalescing_for_single_query_callers(la, po, gpu):
+    """64 threads each issuing single-query search() calls (the serve.rs pattern) are answered by a few
+    batched launches with identical results."""
+    import time
+    X = synth(po, 30000, 128)
+    dX = la.DeviceArray.from_host(X)
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, 30000, 128, 128, 16, 64)
+    Q = synth(po, 64 * 20, 128, stream=1)
+    ref_k, ref_d, _ = s.search_batch(Q, 10, 64)
+    out = {}
+
+    def work(t):
+        for j in range(20):
+            i = t * 20 + j
+            out[i] = s.search(Q[i], 10, 64)
+
+    def run():
+        out.clear()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(64)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return time.perf_counter() - t0
+
+    t_plain = run()
+    for i in range(len(Q)):
+        assert (out[i][0] == ref_k[i]).all() and (out[i][1] == ref_d[i]).all()
+    s.set_coalescing(300, 1024)
+    t_coal = run()
+    for i in range(len(Q)):
+        assert (out[i][0] == ref_k[i]).all() and (out[i][1] == ref_d[i]).all()
+    st = s.coalescing_stats()
+    assert st["queries"] == len(Q) and st["launches"] < len(Q) / 4
+    # mixed (top_k, complexity) in one window are split into separate launches
+    r1, r2 = {}, {}
+    th = [threading.Thread(target=lambda i=i: r1.__setitem__(i, s.search(Q[i], 5, 32))) for i in range(16)]
+    th += [threading.Thread(target=lambda i=i: r2.__setitem__(i, s.search(Q[i], 10, 64))) for i in range(16)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    k5, d5, _ = s.search_batch(Q[:16], 5, 32)
+    for i in range(16):
+        assert (r1[i][0] == k5[i]).all() and (r2[i][0] == ref_k[i]).all()
+    s.set_coalescing(0, 0)
+    assert (s.search(Q[3], 10, 64)[0] == ref_k[3]).all()
+    print(f"single-query callers: plain {len(Q)/t_plain:.0f} q/s, coalesced {len(Q)/t_coal:.0f} q/s, launches {st['launches']}")
+    s.close()
