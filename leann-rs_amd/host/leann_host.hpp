@@ -21,6 +21,7 @@
 #include <fstream>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <set>
 #include <sstream>
@@ -489,8 +490,10 @@ class IndexSearcher {
         std::vector<std::pair<size_t, float>> vector_results;
         for (size_t i = 0; i < n; i++) vector_results.emplace_back((size_t)keys[i], dists[i]); // score = backend distance (N1)
         if (opts.hybrid && opts.query_text) { // :146-169
-            auto all_texts = get_all_texts();
-            Bm25Scorer scorer = Bm25Scorer::build(all_texts);
+            // The reference re-reads every passage and rebuilds the BM25 tables per query (:149-151, :213-224);
+            // the index is immutable while open, so the tables are built once and kept —
+            // scores are identical.
+            const Bm25Scorer &scorer = bm25();
             auto bm25_scores = scorer.score_query(*opts.query_text);
             auto bm25_top = scorer.search(*opts.query_text, fetch_k);
             std::unordered_set<size_t> have;
@@ -522,7 +525,7 @@ class IndexSearcher {
         return texts;
     }
     std::vector<std::string> bm25_search(const std::string &query, size_t top_k) const { // :228-246
-        Bm25Scorer scorer = Bm25Scorer::build(get_all_texts());
+        const Bm25Scorer &scorer = bm25();
         std::vector<std::string> texts;
         for (auto &r : scorer.search(query, top_k))
             if (r.first < id_map_.size()) {
@@ -534,9 +537,16 @@ class IndexSearcher {
     bool is_empty() const { return len() == 0; }
 
   private:
+    const Bm25Scorer &bm25() const {
+        std::lock_guard<std::mutex> lk(*bm25_mu_);
+        if (!bm25_) bm25_ = std::make_shared<Bm25Scorer>(Bm25Scorer::build(get_all_texts()));
+        return *bm25_;
+    }
     PassageStore passages_;
     std::shared_ptr<leann_backend> backend_;
     std::vector<std::string> id_map_;
+    mutable std::shared_ptr<Bm25Scorer> bm25_;
+    std::shared_ptr<std::mutex> bm25_mu_ = std::make_shared<std::mutex>();
 };
 
 // ---- embeddings: the thing RecomputeSearcher calls (src/embedding/mod.rs:112-143) ------------------------

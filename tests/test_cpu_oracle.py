@@ -210,3 +210,19 @@ def test_oracle_under_address_and_ub_sanitizers():
     out = subprocess.run([os.path.join(root, "oracle", "selfcheck")], capture_output=True, text=True,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0 and "selfcheck OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_regression_pins_oracle(po):
+    """tests/golden/pins_v1.npz: bits this implementation produced when GPU == oracle was first established."""
+    z = np.load(os.path.join(GOLD, "pins_v1.npz"))
+    SEED = 0x5EED0001
+    for name, (d, r, C_, sig, stream, i0) in {"c768": (768, 64, 4096, 1.0, 0, 0), "q768": (768, 64, 4096, 1.0, 1, 7),
+                                               "iid128": (128, 0, 1, 0.0, 0, 3), "c1536": (1536, 64, 4096, 1.0, 0, 10 ** 7)}.items():
+        assert (po.gen_rows(SEED, d, r, C_, sig, stream, i0, 3).view(np.uint32)[:, :16] == z["gen_" + name]).all(), name
+    X = po.gen_rows(SEED, 96, 32, 64, 1.0, 0, 0, 2000)
+    Q = po.gen_rows(SEED, 96, 32, 64, 1.0, 1, 0, 16)
+    assert (np.array([po.dot(Q[i], X[i], "canon") for i in range(16)], f32).view(np.uint32) == z["dot_canon"]).all()
+    assert (np.array([po.lib().orc_level(0x5EED0003, i, 32) for i in range(4096)], np.uint8) == z["levels_M32"]).all()
+    Gr = po.Graph.build_hnsw(X, M=8, efc=32)
+    k, dd, c, st = Gr.search_batch(Q, 5, 24, 0, 1)
+    assert (k == z["hnsw_keys"]).all() and (dd.view(np.uint32) == z["hnsw_dists"]).all() and (st == z["hnsw_stats"]).all()

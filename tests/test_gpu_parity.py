@@ -237,3 +237,26 @@ def test_open_errors(la, gpu, tmp_path):
     (tmp_path / "documents.index").write_bytes(b"garbage!" * 32)
     with pytest.raises(la.LeannError, match="incompatible format"):
         la.HnswSearcher.load(stem, 128)
+
+
+def test_regression_pins_gpu(la, po, gpu):
+    """The HIP generator, level hash and traversal reproduce tests/golden/pins_v1.npz bit for bit."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pins_v1.npz"))
+    for name, (d, r, C_, sig, stream, i0) in {"c768": (768, 64, 4096, 1.0, 0, 0), "q768": (768, 64, 4096, 1.0, 1, 7),
+                                               "iid128": (128, 0, 1, 0.0, 0, 3), "c1536": (1536, 64, 4096, 1.0, 0, 10 ** 7)}.items():
+        buf = la.DeviceArray((3, d), np.float32)
+        la._native.check(la.lib().leann_synth_rows_device(SEED, d, d, r, C_, sig, stream, i0, 3, buf.ptr, None))
+        la.sync()
+        assert (buf.to_host().view(np.uint32)[:, :16] == z["gen_" + name]).all(), name
+    X = po.gen_rows(SEED, 96, 32, 64, 1.0, 0, 0, 2000)
+    Q = po.gen_rows(SEED, 96, 32, 64, 1.0, 1, 0, 16)
+    G = po.Graph.build_hnsw(X, M=8, efc=32)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, 8, 16, G.max_level, G.entry, lv, uo, a0, aU)
+    s.stats(reset=True)
+    k, dd, c = s.search_batch(Q, 5, 24)
+    assert (k == z["hnsw_keys"]).all() and (dd.view(np.uint32) == z["hnsw_dists"]).all()
+    st = s.stats()
+    assert st["n_dist_evals"] == int(z["hnsw_stats"][:, 0].sum()) and st["n_hops_base"] == int(z["hnsw_stats"][:, 1].sum())
+    s.close()
