@@ -44,6 +44,9 @@ WORKLOADS = {
     # configs[2]: recompute-on (no stored vectors), batch-64 queries: features [rows x 256] bf16 + W [256 x 768] bf16
     "recompute10m": dict(rows=10_000_000, d=768, h=256, kind="recompute", batch=64),
     "recompute1m": dict(rows=1_000_000, d=768, h=256, kind="recompute", batch=64),
+    # configs[2] with the LEANN idea proper: HNSW whose distances are recomputed from the bf16 features (no stored vectors)
+    "recompute10m_graph": dict(rows=10_000_000, d=768, h=256, M=32, efc=200, ef=128, kind="recompute_graph"),
+    "recompute1m_graph": dict(rows=1_000_000, d=768, h=256, M=32, efc=200, ef=128, kind="recompute_graph"),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = f32 vector peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
@@ -81,9 +84,9 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
     W = torch.empty((h, d), dtype=torch.int16, device=dev)
     Fq = torch.empty((B * 4, h), dtype=torch.int16, device=dev)
     Q = torch.empty((B * 4, ld), dtype=torch.float32, device=dev)
-    chk(L.leann_synth_features_device(SEED, h, GEN_CLUSTERS, GEN_SIGMA, 0, row0, rows, F.data_ptr(), sp))
+    chk(L.leann_synth_features_device(SEED, h, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 0, row0, rows, F.data_ptr(), sp))
     chk(L.leann_synth_weights_device(SEED, h, d, W.data_ptr(), sp))
-    chk(L.leann_synth_features_device(SEED, h, GEN_CLUSTERS, GEN_SIGMA, 1, 0, B * 4, Fq.data_ptr(), sp))
+    chk(L.leann_synth_features_device(SEED, h, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 1, 0, B * 4, Fq.data_ptr(), sp))
     stream.synchronize()
     r, rq = C.c_void_p(), C.c_void_p()
     chk(L.leann_recompute_create(F.data_ptr(), rows, h, W.data_ptr(), d, local_rank, row0, C.byref(r)))
@@ -220,26 +223,52 @@ def main():
     sp = C.c_void_p(stream.cuda_stream)
 
     # ---- synthetic corpus shard + index, all in HBM ---------------------------------------------
+    rgraph = wl.get("kind") == "recompute_graph"
+    n_pool = max(1, min(args.steps, 8))
+    q_first = 0 if (shard or world == 1) else rank * n_pool * B
     t0 = time.time()
-    X = torch.empty((rows, ld), dtype=torch.float32, device=dev)
-    with torch.cuda.stream(stream):
-        chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 0, row0, rows, X.data_ptr(), sp))
-    stream.synchronize()
-    log(f"rank {rank}: corpus rows [{row0}, {row0 + rows}) x {d} generated in {time.time() - t0:.1f}s")
-    t0 = time.time()
-    searcher = la.BackendSearcher.build_device(backend, X.data_ptr(), rows, d, ld, M, efc, device=local_rank,
-                                               key_offset=row0)
+    if rgraph:
+        # no stored vectors: bf16 features + encoder weights; the graph is built on transient embeddings
+        hfeat = wl["h"]
+        F = torch.empty((rows, hfeat), dtype=torch.int16, device=dev)
+        Wt = torch.empty((hfeat, d), dtype=torch.int16, device=dev)
+        chk(L.leann_synth_features_device(SEED, hfeat, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 0, row0, rows, F.data_ptr(), sp))
+        chk(L.leann_synth_weights_device(SEED, hfeat, d, Wt.data_ptr(), sp))
+        stream.synchronize()
+        rc_h = C.c_void_p()
+        chk(L.leann_recompute_create(F.data_ptr(), rows, hfeat, Wt.data_ptr(), d, local_rank, row0, C.byref(rc_h)))
+        log(f"rank {rank}: features [{rows} x {hfeat}] bf16 generated in {time.time() - t0:.1f}s")
+        t0 = time.time()
+        hb = C.c_void_p()
+        chk(L.leann_recompute_build_index(rc_h, backend, M, efc, C.byref(hb)))
+        searcher = la.BackendSearcher(hb, backend)
+        X = None
+    else:
+        X = torch.empty((rows, ld), dtype=torch.float32, device=dev)
+        with torch.cuda.stream(stream):
+            chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 0, row0, rows, X.data_ptr(), sp))
+        stream.synchronize()
+        log(f"rank {rank}: corpus rows [{row0}, {row0 + rows}) x {d} generated in {time.time() - t0:.1f}s")
+        t0 = time.time()
+        searcher = la.BackendSearcher.build_device(backend, X.data_ptr(), rows, d, ld, M, efc, device=local_rank,
+                                                   key_offset=row0)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     gi = searcher.graph_info()
     log(f"rank {rank}: index built on GPU in {build_s:.1f}s ({rows / build_s:.0f} rows/s), max_level={gi['max_level']}")
 
     # ---- queries: a pool of distinct batches, same on every rank in shard mode --------------------
-    n_pool = max(1, min(args.steps, 8))
-    q_first = 0 if (shard or world == 1) else rank * n_pool * B
     Q = torch.empty((n_pool * B, ld), dtype=torch.float32, device=dev)
-    with torch.cuda.stream(stream):
-        chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 1, q_first, n_pool * B, Q.data_ptr(), sp))
+    if rgraph:  # queries = embeddings of query-side features (the provider embeds the query text the same way)
+        Fq = torch.empty((n_pool * B, hfeat), dtype=torch.int16, device=dev)
+        chk(L.leann_synth_features_device(SEED, hfeat, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 1, q_first, n_pool * B, Fq.data_ptr(), sp))
+        rq_h = C.c_void_p()
+        chk(L.leann_recompute_create(Fq.data_ptr(), n_pool * B, hfeat, Wt.data_ptr(), d, local_rank, 0, C.byref(rq_h)))
+        chk(L.leann_recompute_encode_device(rq_h, 0, n_pool * B, Q.data_ptr(), sp))
+        stream.synchronize()
+    else:
+        with torch.cuda.stream(stream):
+            chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 1, q_first, n_pool * B, Q.data_ptr(), sp))
     keys = torch.empty((B, k), dtype=torch.int64, device=dev)
     dists = torch.empty((B, k), dtype=torch.float32, device=dev)
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -270,8 +299,12 @@ def main():
     gt_s = torch.empty((nrq, k), dtype=torch.float32, device=dev)
     gt_c = torch.empty((nrq,), dtype=torch.int32, device=dev)
     t0 = time.time()
-    chk(L.leann_scan_topk_device(X.data_ptr(), rows, d, ld, Q.data_ptr(), nrq, k, None, row0, gt_k.data_ptr(),
-                                 gt_s.data_ptr(), gt_c.data_ptr(), sp))
+    if rgraph:  # exact truth = the brute-force recompute search (fused MFMA kernel) over the same encoder
+        chk(L.leann_recompute_search_batch_device(rc_h, Q.data_ptr(), nrq, k, None, gt_k.data_ptr(), gt_s.data_ptr(),
+                                                  gt_c.data_ptr(), sp))
+    else:
+        chk(L.leann_scan_topk_device(X.data_ptr(), rows, d, ld, Q.data_ptr(), nrq, k, None, row0, gt_k.data_ptr(),
+                                     gt_s.data_ptr(), gt_c.data_ptr(), sp))
     stream.synchronize()
     if shard:  # global truth = merge of per-shard exact lists (scores descending)
         with torch.cuda.stream(stream):
@@ -326,7 +359,8 @@ def main():
     st = st[:used].reshape(-1, 4)
     evals, hops0, hopsU, ovf = [float(x) for x in st.sum(0)]
     nq_stat = st.shape[0]
-    bytes_per_query = (evals * d * 4 + hops0 * gi["M0"] * 4 + hopsU * gi["M"] * 4) / nq_stat
+    row_bytes = 2 * hfeat + 8 if rgraph else d * 4  # recompute-on: 256 bf16 features + f32 norm (+pad) per evaluated neighbour
+    bytes_per_query = (evals * row_bytes + hops0 * gi["M0"] * 4 + hopsU * gi["M"] * 4) / nq_stat
     bytes_per_launch = bytes_per_query * B
     achieved = bytes_per_launch / kern_avg_s / 1e9
     traffic = None
@@ -355,8 +389,10 @@ def main():
         "data": "synthetic",
         "recall_at_10": recall,
         "config": {
-            "workload": f"{args.workload}: {'Vamana R' if backend else 'HNSW M'}={M} efc={efc} ef={ef} k={k}, {rows} x {d} f32 rows per GPU, "
-                        f"batch {B} queries/step, clustered synthetic (r={GEN_R}, C={GEN_CLUSTERS}, sigma={GEN_SIGMA})",
+            "workload": f"{args.workload}: {'Vamana R' if backend else 'HNSW M'}={M} efc={efc} ef={ef} k={k}, {rows} x {d} "
+                        + (f"embeddings per GPU recomputed on the fly from [{rows} x {wl.get('h')}] bf16 features (no stored vectors), " if rgraph
+                           else "f32 rows per GPU, ")
+                        + f"batch {B} queries/step, clustered synthetic (r={GEN_R}, C={GEN_CLUSTERS}, sigma={GEN_SIGMA})",
             "rows_per_gpu": rows, "corpus_rows_total": corpus_total, "dims": d, "M": M, "ef_construction": efc,
             "ef_search": ef, "top_k": k, "batch": B,
             "parallelism": ("single" if world == 1 else (f"shard{world}+rccl_allgather" if shard else f"replica{world}")),
@@ -364,7 +400,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "beam_search_kernel<3,4,4,false>" if ld == 768 else "beam_search_kernel",
+            "traffic": traffic, "kernel": ("beam_search_feat_kernel<1,4,4> (+ score_mfma_kernel query projection)" if rgraph else
+                       "beam_search_kernel<3,4,4,false>" if ld == 768 else "beam_search_kernel"),
             "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_query": bytes_per_query,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "dist_evals_per_query": evals / nq_stat, "hops_per_query": (hops0 + hopsU) / nq_stat,
@@ -382,12 +419,24 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po
             t0 = time.time()
-            g = searcher.graph_export(with_vectors=True)
-            log(f"graph + rows copied to host in {time.time() - t0:.1f}s")
-            G = po.Graph.from_arrays(g["vectors"], g["M"], g["M0"], g["max_level"], g["entry"], g["levels"],
-                                     g["upper_off"], g["adj0"], g["adjU"])
             ncpu = min(args.cpu_queries, B)
-            Qh = Q[:ncpu, :d].contiguous().cpu().numpy()
+            if rgraph:
+                g = searcher.graph_export()
+                fh, rb = C.c_uint32(0), C.c_uint32(0)
+                chk(L.leann_backend_feature_rows_export(searcher._h, C.byref(fh), C.byref(rb), None))
+                rows_b = np.zeros((rows, rb.value), np.uint8)
+                chk(L.leann_backend_feature_rows_export(searcher._h, None, None, rows_b.ctypes.data))
+                G = po.Graph.from_arrays(np.zeros((rows, 1), np.float32), g["M"], g["M0"], g["max_level"], g["entry"], g["levels"],
+                                         g["upper_off"], g["adj0"], g["adjU"])
+                G.set_features(rows_b, fh.value, rb.value)
+                ncpu = min(ncpu, 2048)
+                Qh = po.project_queries(Wt.cpu().numpy().view(np.uint16), Q[:ncpu, :d].contiguous().cpu().numpy(), fh.value)
+            else:
+                g = searcher.graph_export(with_vectors=True)
+                G = po.Graph.from_arrays(g["vectors"], g["M"], g["M0"], g["max_level"], g["entry"], g["levels"],
+                                         g["upper_off"], g["adj0"], g["adjU"])
+                Qh = Q[:ncpu, :d].contiguous().cpu().numpy()
+            log(f"graph + rows copied to host in {time.time() - t0:.1f}s")
             cores = host_cores()
             G.search_batch(Qh[: min(256, ncpu)], k, ef, 0, cores)  # touch
             t0 = time.perf_counter()

@@ -170,8 +170,16 @@ size_t leann_recompute_len(const leann_recompute *r);
 /* HIP-event milliseconds of the last search call: [0] encode GEMM, [1] scoring GEMM, [2] top-k */
 int leann_recompute_last_timing(const leann_recompute *r, float *ms3);
 void leann_recompute_close(leann_recompute *r);
+/* Recompute-on GRAPH index: HNSW / Vamana whose distances are recomputed from the encoder inputs.  The graph is
+ * built on transiently materialised embeddings; the returned searcher keeps the graph, the bf16 features and one
+ * f32 per passage (||W^T f||) — no vectors — and evaluates dist = 1 - <f, W q> / ||W^T f|| (== 1 - <e, q>).
+ * It is an ordinary leann_backend handle: leann_backend_search* work unchanged (queries in embedding space). */
+int leann_recompute_build_index(const leann_recompute *r, int backend, size_t graph_degree, size_t complexity,
+                                leann_backend **out);
+int leann_backend_feature_rows_export(const leann_backend *h, uint32_t *feat_h, uint32_t *row_bytes, void *out);
 /* synthetic encoder inputs (bf16), the recompute twin of leann_synth_rows_device */
-int leann_synth_features_device(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma,
+/* r_int = 0: h-dimensional cluster+noise features; r_int > 0: intrinsic dimension r_int lifted to width h */
+int leann_synth_features_device(uint64_t seed, uint32_t h, uint32_t r_int, uint32_t n_clusters, float sigma,
                                 uint32_t stream_id, uint64_t i0, uint64_t n, uint16_t *d_out, void *stream);
 int leann_synth_weights_device(uint64_t seed, uint32_t h, uint32_t dims, uint16_t *d_out, void *stream);
 

@@ -66,7 +66,9 @@ SIGNATURES = {
     "leann_recompute_len": (C.c_size_t, [vp]),
     "leann_recompute_last_timing": (C.c_int, [vp, f32p]),
     "leann_recompute_close": (None, [vp]),
-    "leann_synth_features_device": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64,
+    "leann_recompute_build_index": (C.c_int, [vp, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
+    "leann_backend_feature_rows_export": (C.c_int, [vp, u32p, u32p, vp]),
+    "leann_synth_features_device": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64,
                                              C.c_uint64, vp, vp]),
     "leann_synth_weights_device": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]),
     "leann_merge_topk_device": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,

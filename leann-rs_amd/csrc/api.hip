@@ -96,6 +96,8 @@ void leann_internal_free_graph(leann_backend *h) {
     (void)hipFree(h->d_levels);
     (void)hipFree(h->gpool);
     (void)hipFree(h->gpool_lock);
+    (void)hipFree(h->Wf32);
+    for (auto &kv : h->proj_scratch) (void)hipFree(kv.second.first);
 }
 
 extern "C" void leann_backend_close(leann_backend *h) {
@@ -171,8 +173,72 @@ static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t 
     return launch_search_NW<T, R, 4>(g, a, st);
 }
 
+template <int T, int R>
+static int launch_search_feat(const GraphView &g, const SearchArgs &a, hipStream_t st) {
+    const uint32_t maxdeg = std::max(g.M0, g.M);
+    size_t lds = search_lds_bytes(a.ef, maxdeg, a.hash_bits);
+    if (lds > 160 * 1024) {
+        leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, lds);
+        return LEANN_ERR_INVALID;
+    }
+    if (a.nq <= 512) {
+        if (lds > 64 * 1024)
+            HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_feat_kernel<T, R, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((beam_search_feat_kernel<T, R, 16>), dim3(a.nq), dim3(16 * 64), lds, st, g, a);
+    } else {
+        if (lds > 64 * 1024)
+            HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_feat_kernel<T, R, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((beam_search_feat_kernel<T, R, 4>), dim3(a.nq), dim3(4 * 64), lds, st, g, a);
+    }
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
+}
+
+// recompute-on mode: queries [nq x dims] -> g = W q [nq x feat_h] into the stream's scratch (f32 MFMA, k-ordered chains)
+static int project_queries(leann_backend *h, const float *d_queries, size_t nq, hipStream_t st, const float **out) {
+    float *G = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        auto &sc = h->proj_scratch[st];
+        const size_t need = nq * h->g.feat_h;
+        if (sc.second < need) {
+            (void)hipFree(sc.first);
+            sc.first = nullptr;
+            sc.second = 0;
+            if (hipMalloc((void **)&sc.first, need * 4) != hipSuccess) { leann_set_error("hipMalloc(%zu) failed", need * 4); return LEANN_ERR_DEVICE; }
+            sc.second = need;
+        }
+        G = sc.first;
+    }
+    int rc = leann_internal_score(h->Wf32, h->g.feat_h, h->g.d, h->g.d, d_queries, nq, h->g.d, G, st);
+    *out = G;
+    return rc;
+}
+
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st) {
     if (a.nq == 0) return LEANN_OK;
+    if (h->g.feat_h) {
+        if (a.q_rows) { leann_set_error("recompute-on index: construction searches are not supported"); return LEANN_ERR_UNSUPPORTED; }
+        if (a.ef < a.k) a.ef = a.k;
+        // 520-B rows make this mode latency- rather than bandwidth-bound: favour occupancy (16 KiB visited table ->
+        // 6-8 workgroups per CU) for narrow beams; heavier queries migrate to the HBM pool
+        a.hash_bits = getenv("LEANN_DEBUG_HASH_BITS") ? pick_hash_bits(a.ef) : (a.ef <= 64 ? 12u : pick_hash_bits(a.ef));
+        int rc = ensure_gpool(h);
+        if (rc) return rc;
+        a.gpool = h->gpool; a.gpool_lock = h->gpool_lock; a.gpool_ctr = h->gpool_ctr;
+        const float *G = nullptr;
+        rc = project_queries(h, a.queries, a.nq, st, &G);
+        if (rc) return rc;
+        a.queries = G;
+        a.ldq = h->g.feat_h;
+        const int T = (int)((h->g.feat_h + 255) / 256);
+        switch (T) {
+            case 1: return launch_search_feat<1, 4>(h->g, a, st);
+            case 2: return launch_search_feat<2, 6>(h->g, a, st);
+            case 3: case 4: return launch_search_feat<4, 4>(h->g, a, st);
+            default: leann_set_error("recompute-on index: feature width %u > 1024 not supported", h->g.feat_h); return LEANN_ERR_INVALID;
+        }
+    }
     if (a.ef < a.k) a.ef = a.k; // diskann.rs:54
     a.hash_bits = pick_hash_bits(a.ef);
     int rc = ensure_gpool(h);
@@ -303,7 +369,7 @@ extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *
             h->stats.n_hops_base += hstats[i * 4 + 1];
             h->stats.n_hops_upper += hstats[i * 4 + 2];
             h->stats.n_table_overflow += hstats[i * 4 + 3];
-            h->stats.algorithmic_bytes += (uint64_t)hstats[i * 4 + 0] * d * 4 + (uint64_t)hstats[i * 4 + 1] * h->g.M0 * 4 +
+            h->stats.algorithmic_bytes += (uint64_t)hstats[i * 4 + 0] * (h->g.feat_h ? h->g.row_bytes : d * 4) + (uint64_t)hstats[i * 4 + 1] * h->g.M0 * 4 +
                                           (uint64_t)hstats[i * 4 + 2] * h->g.M * 4;
         }
         h->stats.n_queries += nq;
@@ -518,6 +584,7 @@ extern "C" int leann_backend_graph_export(const leann_backend *h, uint8_t *level
     if (adj0) HIP_CHECK_RET(hipMemcpy(adj0, h->g.adj0, n * h->g.M0 * 4, hipMemcpyDeviceToHost));
     if (adjU && h->n_upper_lists)
         HIP_CHECK_RET(hipMemcpy(adjU, h->g.adjU, h->n_upper_lists * h->g.M * 4, hipMemcpyDeviceToHost));
+    if (vectors && h->g.feat_h) { leann_set_error("graph_export: a recompute-on index holds no vectors"); return LEANN_ERR_UNSUPPORTED; }
     if (vectors)
         HIP_CHECK_RET(hipMemcpy2D(vectors, (size_t)h->g.d * 4, h->g.X, (size_t)h->g.ld * 4, (size_t)h->g.d * 4, n,
                                   hipMemcpyDeviceToHost));
@@ -553,6 +620,7 @@ struct FileHeader {
 
 extern "C" int leann_backend_save(const leann_backend *h, const char *index_path_stem) {
     if (!h || !index_path_stem) { leann_set_error("leann_backend_save: null argument"); return LEANN_ERR_INVALID; }
+    if (h->g.feat_h) { leann_set_error("leann_backend_save: a recompute-on index holds no vectors to save"); return LEANN_ERR_UNSUPPORTED; }
     std::string path = leann_internal_index_file(index_path_stem, h->kind);
     const size_t n = h->g.n, d = h->g.d;
     std::vector<uint8_t> levels(std::max<size_t>(n, 1));

@@ -32,9 +32,15 @@ struct leann_backend {
     unsigned long long *gpool = nullptr;
     uint32_t *gpool_lock = nullptr, *gpool_ctr = nullptr;
     leann_search_stats stats{};
+    // recompute-on graph mode (g.feat_h != 0): encoder weights as f32 [feat_h x dims] for the query projection and
+    // per-stream scratch for the projected queries
+    float *Wf32 = nullptr;
+    std::map<hipStream_t, std::pair<float *, size_t>> proj_scratch;
     Coalescer *coalescer = nullptr; // optional request coalescing for single-query callers (api.hip)
 };
 
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st);
+int leann_internal_score(const float *X, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t ldq, float *S,
+                         hipStream_t st);
 void leann_internal_free_graph(leann_backend *h);
 std::string leann_internal_index_file(const char *stem, int backend);

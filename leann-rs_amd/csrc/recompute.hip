@@ -18,6 +18,7 @@
 // E lives only in a chunk-sized scratch buffer (never N x d).
 #include "common.cuh"
 #include "../../include/leann_backend.h"
+#include "internal.h"
 #include <algorithm>
 #include <vector>
 
@@ -42,28 +43,56 @@ __host__ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 #define TAG_C 0x43454E5400000000ull
 #define TAG_A 0x4153534700000000ull
 #define TAG_N 0x4E4F495300000000ull
-__global__ void synth_features_kernel(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma, uint32_t stream_id,
-                                      uint64_t i0, uint64_t n, uint16_t *__restrict__ out) {
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * h) return;
-    const uint64_t ii = idx / h, i = i0 + ii;
-    const uint32_t k = (uint32_t)(idx % h);
+#define TAG_F 0x4645415400000000ull /* feature lift */
+// r_int == 0: f = bf16(z), z in R^h.   r_int > 0: z in R^r_int (clusters + noise, as gen.hip), f[k] = bf16(sum_m A[k][m] z[m])
+// (fmaf chain in increasing m) — features of width h with intrinsic dimension r_int, like real encoder inputs.
+__global__ void __launch_bounds__(256) synth_features_kernel(uint64_t seed, uint32_t h, uint32_t r_int, uint32_t n_clusters, float sigma,
+                                                             uint32_t stream_id, uint64_t i0, uint64_t n, uint16_t *__restrict__ out) {
+    extern __shared__ float s_feat[]; // [h * r_int] lift matrix A, then [r_int] z
     const uint64_t nseed = seed ^ TAG_N ^ ((uint64_t)stream_id * 0x9E3779B97F4A7C15ull);
-    const uint64_t c = hash3(seed ^ TAG_A, stream_id, i) % n_clusters;
-    out[idx] = f32_to_bf16_rne(fmaf(sigma, gauss_ih4(nseed, i, k), gauss_ih4(seed ^ TAG_C, c, k)));
+    if (r_int == 0) {
+        for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * h; idx += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t i = i0 + idx / h;
+            const uint32_t k = (uint32_t)(idx % h);
+            const uint64_t c = hash3(seed ^ TAG_A, stream_id, i) % n_clusters;
+            out[idx] = f32_to_bf16_rne(fmaf(sigma, gauss_ih4(nseed, i, k), gauss_ih4(seed ^ TAG_C, c, k)));
+        }
+        return;
+    }
+    float *A = s_feat, *z = s_feat + (size_t)h * r_int;
+    for (uint32_t idx = threadIdx.x; idx < h * r_int; idx += blockDim.x) A[idx] = gauss_ih4(seed ^ TAG_F, idx / r_int, idx % r_int);
+    for (uint64_t ii = blockIdx.x; ii < n; ii += gridDim.x) {
+        const uint64_t i = i0 + ii;
+        const uint64_t c = hash3(seed ^ TAG_A, stream_id, i) % n_clusters;
+        __syncthreads();
+        for (uint32_t m = threadIdx.x; m < r_int; m += blockDim.x)
+            z[m] = fmaf(sigma, gauss_ih4(nseed, i, m), gauss_ih4(seed ^ TAG_C, c, m));
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < h; k += blockDim.x) {
+            float acc = 0.f;
+            for (uint32_t m = 0; m < r_int; m++) acc = fmaf(A[k * r_int + m], z[m], acc);
+            out[ii * h + k] = f32_to_bf16_rne(acc);
+        }
+    }
 }
 __global__ void synth_weights_kernel(uint64_t seed, uint32_t h, uint32_t d, uint16_t *__restrict__ W /* [h x d] */) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= h * d) return;
     W[idx] = f32_to_bf16_rne(gauss_ih4(seed ^ TAG_P, idx / d, idx % d));
 }
-extern "C" int leann_synth_features_device(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma, uint32_t stream_id,
-                                           uint64_t i0, uint64_t n, uint16_t *d_out, void *stream) {
-    if (!d_out || h == 0 || n_clusters == 0) { leann_set_error("leann_synth_features_device: invalid arguments"); return LEANN_ERR_INVALID; }
+extern "C" int leann_synth_features_device(uint64_t seed, uint32_t h, uint32_t r_int, uint32_t n_clusters, float sigma,
+                                           uint32_t stream_id, uint64_t i0, uint64_t n, uint16_t *d_out, void *stream) {
+    if (!d_out || h == 0 || n_clusters == 0 || (size_t)(h + 1) * r_int * 4 > 150 * 1024) {
+        leann_set_error("leann_synth_features_device: invalid arguments (h=%u r_int=%u)", h, r_int);
+        return LEANN_ERR_INVALID;
+    }
     if (n == 0) return LEANN_OK;
-    const uint64_t total = n * h;
-    hipLaunchKernelGGL(synth_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, h,
-                       n_clusters, sigma, stream_id, i0, n, d_out);
+    const size_t lds = r_int ? ((size_t)h * r_int + r_int) * 4 : 0;
+    if (lds > 64 * 1024)
+        HIP_CHECK_RET(hipFuncSetAttribute((const void *)synth_features_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const uint64_t blocks = r_int ? std::min<uint64_t>(n, 4096) : std::min<uint64_t>((n * h + 255) / 256, 65536);
+    hipLaunchKernelGGL(synth_features_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, seed, h, r_int, n_clusters,
+                       sigma, stream_id, i0, n, d_out);
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
 }
@@ -129,7 +158,7 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
                                                      const uint16_t *__restrict__ Wp, uint32_t d, uint32_t ld_out,
                                                      float *__restrict__ E, const uint16_t *__restrict__ Gp, uint32_t nq,
                                                      float *__restrict__ S, uint32_t n_rows_s, uint32_t L,
-                                                     const uint8_t *__restrict__ mask) {
+                                                     const uint8_t *__restrict__ mask, float *__restrict__ norms_out) {
     constexpr int DP = CT * 128;              // padded columns of W
     constexpr int DPX = DP + (FUSED ? 192 : 0); // + three 64-query pieces of G
     constexpr int RING = 3;                     // k-step slabs in LDS: one being consumed, two in flight
@@ -331,6 +360,7 @@ __global__ void __launch_bounds__(512) encode_kernel(const uint16_t *__restrict_
             float nrm = sqrtf(ss);
             nrm = nrm < 1e-12f ? 1e-12f : nrm;
             if (row < n && (r % L) == 0) {
+                if (norms_out && cgrp == 0 && l31 == 0) norms_out[row / L] = nrm; // ||W^T f|| before normalisation
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
                     const uint32_t col = (cgrp * CT + ct) * 32 + l31;
@@ -358,7 +388,7 @@ struct leann_recompute {
 static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { return 128 * (hp + 8) * 2 + 3 * (dp + (fused ? 192 : 0)) * 16 * 2 + 6 * 128 * 4; }
 
 static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st,
-                         const uint16_t *Gp = nullptr, uint32_t nq = 0, float *S = nullptr) {
+                         const uint16_t *Gp = nullptr, uint32_t nq = 0, float *S = nullptr, float *norms = nullptr) {
     const bool fused = Gp != nullptr;
     const size_t lds = encode_lds_bytes(r->hp, r->dp, fused);
     // row0 / rows count PASSAGES; the kernel works on token rows (L per passage, tiles of 128 token rows)
@@ -371,7 +401,7 @@ static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows,
         HIP_CHECK_RET(hipFuncSetAttribute((const void *)encode_kernel<CT, FU, PO>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                           160 * 1024));                                                                   \
         hipLaunchKernelGGL((encode_kernel<CT, FU, PO>), dim3(grid), dim3(512), lds, st, F, (uint64_t)toks, (uint32_t)r->h,        \
-                           (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E, Gp, nq, S, (uint32_t)rows, r->L, mk);      \
+                           (uint32_t)r->hp, r->Wp, (uint32_t)r->d, (uint32_t)r->ld, E, Gp, nq, S, (uint32_t)rows, r->L, mk, norms); \
     } while (0)
 #define LAUNCH_CT(CT)                                                                                                     \
     do {                                                                                                                  \
@@ -566,4 +596,84 @@ extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, con
     (void)hipFree(candB);
     (void)hipFree(best);
     return rc;
+}
+
+// ================================================================================================
+// Recompute-on GRAPH search (the LEANN idea proper: a graph index whose distances are recomputed from the
+// encoder inputs instead of stored vectors).  The graph is built once on transiently materialised embeddings;
+// afterwards the index keeps only the graph, the bf16 features and one f32 per passage (||W^T f||):
+//     dist(q, i) = 1 - <f_i, W q> / ||W^T f_i||   ==   1 - <l2norm(W^T f_i), q>
+// 520 B per evaluated neighbour instead of 3 072 B (h = 256, d = 768).  The traversal kernel is the same
+// (search.cuh, FEAT instantiation); queries are projected once per batch (g = W q, f32 MFMA).
+// ================================================================================================
+__global__ void pack_feature_rows_kernel(const uint16_t *__restrict__ F, const float *__restrict__ norms, uint64_t n, uint32_t h,
+                                         uint32_t hp4, uint32_t row_bytes, unsigned char *__restrict__ out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // (row, element) incl. the norm slot
+    const uint32_t per = hp4 + 2;                                         // hp4 bf16 + one f32 (= 2 bf16 slots)
+    if (idx >= n * per) return;
+    const uint64_t row = idx / per;
+    const uint32_t e = (uint32_t)(idx % per);
+    unsigned char *dst = out + row * row_bytes;
+    if (e < hp4) reinterpret_cast<uint16_t *>(dst)[e] = e < h ? F[row * h + e] : (uint16_t)0;
+    else if (e == hp4) *reinterpret_cast<float *>(dst + 2 * (size_t)hp4) = norms[row];
+}
+__global__ void bf16_to_f32_kernel(const uint16_t *__restrict__ in, size_t n, float *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __uint_as_float((uint32_t)in[i] << 16);
+}
+
+extern "C" int leann_recompute_build_index(const leann_recompute *r, int backend, size_t graph_degree, size_t complexity,
+                                           leann_backend **out) {
+    if (!r || !out) { leann_set_error("leann_recompute_build_index: null argument"); return LEANN_ERR_INVALID; }
+    if (r->L != 1 || r->mask) {
+        leann_set_error("recompute-on graph search needs one feature vector per passage (no token pooling): the feature-space "
+                        "distance <f, W q> / ||W^T f|| is only exact for bf16-exact features");
+        return LEANN_ERR_UNSUPPORTED;
+    }
+    HIP_CHECK_RET(hipSetDevice(r->device));
+    const size_t n = r->n, ld = r->ld;
+    float *E = nullptr, *norms = nullptr;
+    HIP_CHECK_RET(hipMalloc((void **)&E, std::max<size_t>(n * ld, 4) * 4));
+    HIP_CHECK_RET(hipMalloc((void **)&norms, std::max<size_t>(n, 1) * 4));
+    int rc = LEANN_OK;
+    for (size_t row0 = 0; row0 < n && rc == LEANN_OK; row0 += (size_t)4 << 20) { // transient embeddings, only for construction
+        const size_t rows = std::min<size_t>((size_t)4 << 20, n - row0);
+        rc = launch_encode(r, row0, rows, E + row0 * ld, nullptr, nullptr, 0, nullptr, norms + row0);
+    }
+    if (rc == LEANN_OK) HIP_CHECK_RET(hipDeviceSynchronize());
+    leann_backend *h = nullptr;
+    if (rc == LEANN_OK) rc = leann_backend_build_device(backend, E, n, r->d, ld, graph_degree, complexity, r->device, r->key_offset, 0, &h);
+    if (rc != LEANN_OK) { (void)hipFree(E); (void)hipFree(norms); return rc; }
+    // swap the rows: features + inline norm replace the embeddings
+    const uint32_t hp4 = (uint32_t)((r->h + 3) & ~(size_t)3);
+    const uint32_t row_bytes = (2 * hp4 + 4 + 7) & ~7u;
+    unsigned char *rows_b = nullptr;
+    HIP_CHECK_RET(hipMalloc((void **)&rows_b, std::max<size_t>(n, 1) * row_bytes));
+    HIP_CHECK_RET(hipMemset(rows_b, 0, std::max<size_t>(n, 1) * row_bytes));
+    const uint64_t total = (uint64_t)n * (hp4 + 2);
+    if (total)
+        hipLaunchKernelGGL(pack_feature_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, r->F, norms, (uint64_t)n,
+                           (uint32_t)r->h, hp4, row_bytes, rows_b);
+    HIP_CHECK_RET(hipMalloc((void **)&h->Wf32, (size_t)hp4 * r->d * 4));
+    HIP_CHECK_RET(hipMemset(h->Wf32, 0, (size_t)hp4 * r->d * 4));
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((r->h * r->d + 255) / 256)), dim3(256), 0, nullptr, r->Wraw, r->h * r->d, h->Wf32);
+    HIP_CHECK_RET(hipGetLastError());
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    (void)hipFree(E);
+    (void)hipFree(norms);
+    h->g.X = reinterpret_cast<const float *>(rows_b);
+    h->owns_rows = true;
+    h->g.feat_h = hp4;
+    h->g.row_bytes = row_bytes;
+    *out = h;
+    return LEANN_OK;
+}
+
+// raw feature rows [n x row_bytes] of a recompute-on index (tests: the oracle walks the same bytes)
+extern "C" int leann_backend_feature_rows_export(const leann_backend *h, uint32_t *feat_h, uint32_t *row_bytes, void *out) {
+    if (!h || !h->g.feat_h) { leann_set_error("not a recompute-on index"); return LEANN_ERR_INVALID; }
+    if (feat_h) *feat_h = h->g.feat_h;
+    if (row_bytes) *row_bytes = h->g.row_bytes;
+    if (out) HIP_CHECK_RET(hipMemcpy(out, h->g.X, (size_t)h->g.n * h->g.row_bytes, hipMemcpyDeviceToHost));
+    return LEANN_OK;
 }

@@ -187,6 +187,17 @@ __global__ void finalize_scan_kernel(const uint64_t *__restrict__ keys, uint32_t
     }
 }
 
+// S[q][row] = <X[row], Q[q]> for all rows (k-ordered f32 fmaf chains on the f32 matrix cores); also used to project
+// queries into feature space (X = encoder weights) for the recompute-on graph search
+int leann_internal_score(const float *X, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t ldq, float *S,
+                         hipStream_t st) {
+    dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
+    hipLaunchKernelGGL(score_mfma_kernel, g1, dim3(256), 0, st, X, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld, d_queries, (uint32_t)nq,
+                       (uint32_t)ldq, (uint64_t)0, (uint32_t)rows, S);
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
+}
+
 __global__ void update_best_kernel(const uint64_t *__restrict__ cand, uint32_t cand_stride_q, uint32_t seg_off, uint32_t n_segs,
                                    uint32_t k, uint64_t *__restrict__ best);
 // one chunk: scores of rows [0, rows) of Xbase against all queries, per-segment top-k appended to cand

@@ -24,6 +24,10 @@ struct GraphView {
     const uint32_t *upper_off; // [n] first upper list of a node (list of level l at upper_off+l-1)
     uint64_t n;
     uint32_t d, ld, M, M0, max_level, entry;
+    // recompute-on graph search (no stored vectors): X points at feature rows instead —
+    // [feat_h bf16 features][f32 ||W^T f||][pad], `row_bytes` apart; the query side is g = W q (feat_h f32) and
+    // dist = 1 - <f, g> / ||W^T f||  ==  1 - <l2norm(W^T f), q>.  feat_h == 0: plain f32 rows.
+    uint32_t feat_h, row_bytes;
 };
 
 // Pool of visited tables in HBM for the rare query whose LDS table fills up: GPOOL_TABLES tables of
@@ -105,6 +109,43 @@ __device__ __forceinline__ void wave_dist_rows(const float4 (&q)[T], const float
     }
 }
 
+// Same for bf16 feature rows with the inline norm (recompute-on mode).  Lane l owns elements 256t+4l..+3 again
+// (one 8-byte load per chunk), so the canonical accumulation order is unchanged; only the operands differ.
+template <int T, int R>
+__device__ __forceinline__ void wave_dist_rows_feat(const float4 (&q)[T], const char *__restrict__ Xb, uint32_t row_bytes,
+                                                    uint32_t h, const uint32_t (&ids)[R], int nrows, int lane, float (&out)[R]) {
+    uint2 v[R][T];
+    float nrm[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (r < nrows) {
+            const char *row = Xb + (size_t)ids[r] * row_bytes;
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const uint32_t j = 256u * t + 4u * lane;
+                v[r][t] = j < h ? *reinterpret_cast<const uint2 *>(row + 2 * (size_t)j) : make_uint2(0u, 0u);
+            }
+            nrm[r] = *reinterpret_cast<const float *>(row + 2 * (size_t)h);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (r < nrows) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                float4 x;
+                x.x = __uint_as_float(v[r][t].x << 16);
+                x.y = __uint_as_float(v[r][t].x & 0xFFFF0000u);
+                x.z = __uint_as_float(v[r][t].y << 16);
+                x.w = __uint_as_float(v[r][t].y & 0xFFFF0000u);
+                fma4(acc, q[t], x);
+            }
+            out[r] = 1.0f - wave_tree_sum(lane4_sum(acc)) / nrm[r];
+        }
+    }
+}
+
 // LDS carve-up (dynamic): [W0 | W1 | s_key | s_new | misc | table]
 struct SearchLds {
     uint64_t *s_key;
@@ -119,7 +160,7 @@ __host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg,
     return b + ((size_t)1 << hash_bits) * 4;
 }
 
-template <int T, int R, int NW>
+template <int T, int R, int NW, bool FEAT>
 __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_t qi, unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ef = a.ef;
@@ -143,8 +184,8 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     float4 q[T];
     {
         const float *qv;
-        uint32_t dq = g.d;
-        if (a.q_rows) qv = g.X + (size_t)a.q_rows[qi] * g.ld;
+        uint32_t dq = FEAT ? g.feat_h : g.d;
+        if (!FEAT && a.q_rows) qv = g.X + (size_t)a.q_rows[qi] * g.ld;
         else qv = a.queries + (size_t)qi * a.ldq;
 #pragma unroll
         for (int t = 0; t < T; t++) q[t] = vec_load4_guard(qv, dq, t, lane);
@@ -156,7 +197,8 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     {
         uint32_t ids[1] = {g.entry};
         float dd[1];
-        wave_dist_rows<T, 1>(q, g.X, g.ld, ids, 1, lane, dd);
+        if (FEAT) wave_dist_rows_feat<T, 1>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, 1, lane, dd);
+        else wave_dist_rows<T, 1>(q, g.X, g.ld, ids, 1, lane, dd);
         best = make_key(dd[0], g.entry); // every wave computes the same value
     }
 
@@ -261,7 +303,8 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     uint32_t j = j0 + r * NW;
                     if (j < n_new) { ids[r] = s.s_new[j]; nrows = r + 1; }
                 }
-                wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
+                if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd);
+                else wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
                 if (lane == 0) {
 #pragma unroll
                     for (int r = 0; r < R; r++)
@@ -360,5 +403,13 @@ __global__ void __launch_bounds__(NW * 64) beam_search_kernel(GraphView g, Searc
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t qi = blockIdx.x;
     if (qi >= a.nq) return;
-    beam_search_one<T, R, NW>(g, a, qi, smem);
+    beam_search_one<T, R, NW, false>(g, a, qi, smem);
+}
+// recompute-on instantiation: rows are bf16 features + inline norm, queries are W q
+template <int T, int R, int NW>
+__global__ void __launch_bounds__(NW * 64) beam_search_feat_kernel(GraphView g, SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    beam_search_one<T, R, NW, true>(g, a, qi, smem);
 }

@@ -240,14 +240,33 @@ static inline float bf16_f32(uint16_t b) {
     memcpy(&f, &u, 4);
     return f;
 }
-void orc_synth_features(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma, uint32_t stream,
+#define TAG_F 0x4645415400000000ull
+void orc_synth_features(uint64_t seed, uint32_t h, uint32_t r_int, uint32_t n_clusters, float sigma, uint32_t stream,
                         uint64_t i0, uint64_t n, uint16_t *out) {
     uint64_t nseed = seed ^ TAG_N ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ull);
+    float *A = NULL, *z = NULL;
+    if (r_int) {
+        A = (float *)malloc((size_t)h * r_int * sizeof(float));
+        z = (float *)malloc((size_t)r_int * sizeof(float));
+        for (uint32_t k = 0; k < h; k++)
+            for (uint32_t m = 0; m < r_int; m++) A[(size_t)k * r_int + m] = orc_gauss(seed ^ TAG_F, k, m);
+    }
     for (uint64_t ii = 0; ii < n; ii++) {
         uint64_t i = i0 + ii, c = orc_hash3(seed ^ TAG_A, stream, i) % n_clusters;
-        for (uint32_t k = 0; k < h; k++)
-            out[ii * h + k] = orc_bf16_rne(fmaf(sigma, orc_gauss(nseed, i, k), orc_gauss(seed ^ TAG_C, c, k)));
+        if (!r_int) {
+            for (uint32_t k = 0; k < h; k++)
+                out[ii * h + k] = orc_bf16_rne(fmaf(sigma, orc_gauss(nseed, i, k), orc_gauss(seed ^ TAG_C, c, k)));
+            continue;
+        }
+        for (uint32_t m = 0; m < r_int; m++) z[m] = fmaf(sigma, orc_gauss(nseed, i, m), orc_gauss(seed ^ TAG_C, c, m));
+        for (uint32_t k = 0; k < h; k++) {
+            float acc = 0.0f;
+            for (uint32_t m = 0; m < r_int; m++) acc = fmaf(A[(size_t)k * r_int + m], z[m], acc);
+            out[ii * h + k] = orc_bf16_rne(acc);
+        }
     }
+    free(A);
+    free(z);
 }
 void orc_synth_weights(uint64_t seed, uint32_t h, uint32_t d, uint16_t *out) {
     for (uint32_t k = 0; k < h; k++)
@@ -307,6 +326,9 @@ struct orc_graph {
     uint32_t *adjU;
     uint64_t n_upper_lists;
     int owns;
+    /* recompute-on mode: rows are [feat_h bf16 features][f32 ||W^T f||][pad], row_bytes apart; queries are g = W q */
+    const unsigned char *Xb;
+    uint32_t feat_h, row_bytes;
 };
 
 uint32_t orc_level(uint64_t seed, uint64_t i, uint32_t M) {
@@ -331,13 +353,23 @@ static inline const uint32_t *nbrs(const orc_graph *g, uint32_t node, uint32_t l
     return g->adjU + ((size_t)g->upper_off[node] + (level - 1)) * g->M;
 }
 static inline void prefetch_row(const orc_graph *g, uint32_t id) {
-    const char *p = (const char *)(g->X + (size_t)id * g->ld);
+    const char *p = g->feat_h ? (const char *)(g->Xb + (size_t)id * g->row_bytes) : (const char *)(g->X + (size_t)id * g->ld);
     __builtin_prefetch(p, 0, 0);
     __builtin_prefetch(p + 64, 0, 0);
     __builtin_prefetch(p + 128, 0, 0);
     __builtin_prefetch(p + 192, 0, 0);
 }
+static inline float bf16_f32(uint16_t b);
+static float gdist_feat(const orc_graph *g, const float *q, uint32_t id) {
+    const unsigned char *row = g->Xb + (size_t)id * g->row_bytes;
+    const uint16_t *f = (const uint16_t *)row;
+    float x[1024], nrm;
+    for (uint32_t j = 0; j < g->feat_h; j++) x[j] = bf16_f32(f[j]);
+    memcpy(&nrm, row + 2 * (size_t)g->feat_h, 4);
+    return 1.0f - orc_dot_canon(q, x, g->feat_h) / nrm; /* csrc/search.cuh: wave_dist_rows_feat */
+}
 static inline float gdist(const orc_graph *g, const float *q, uint32_t id) {
+    if (g->feat_h) return gdist_feat(g, q, id);
     if (g_fast_dot) return 1.0f - orc_dot_fast(q, g->X + (size_t)id * g->ld, g->d);
     return 1.0f - orc_dot_canon(q, g->X + (size_t)id * g->ld, g->d);
 }
@@ -816,6 +848,22 @@ orc_graph *orc_graph_from_arrays(const float *X, uint64_t n, uint32_t d, uint32_
     g->n_upper_lists = n_upper_lists;
     g->owns = 0;
     return g;
+}
+/* recompute-on: attach feature rows (borrowed); queries passed to orc_graph_search* are then g = W q (feat_h f32) */
+void orc_graph_set_features(orc_graph *g, const unsigned char *rows, uint32_t feat_h, uint32_t row_bytes) {
+    g->Xb = rows;
+    g->feat_h = feat_h;
+    g->row_bytes = row_bytes;
+    g->d = feat_h; /* query stride of the batch API */
+}
+/* g[k] = sum_j W[k][j] * q[j], one k-ordered fmaf chain per k (f32 MFMA order of csrc/scan.hip:score_mfma_kernel) */
+void orc_project_query(const uint16_t *W, uint32_t h, uint32_t hp4, uint32_t d, const float *q, float *gq) {
+    for (uint32_t k = 0; k < hp4; k++) {
+        float s = 0.0f;
+        if (k < h)
+            for (uint32_t j = 0; j < d; j++) s = fmaf(bf16_f32(W[(size_t)k * d + j]), q[j], s);
+        gq[k] = s;
+    }
 }
 void orc_graph_info(const orc_graph *g, uint64_t *out) {
     out[0] = g->n;

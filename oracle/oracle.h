@@ -80,6 +80,8 @@ orc_graph *orc_graph_from_arrays(const float *X, uint64_t n, uint32_t d, uint32_
                                  uint32_t M0, uint32_t max_level, uint32_t entry,
                                  const uint8_t *levels, const uint32_t *upper_off,
                                  const uint32_t *adj0, const uint32_t *adjU, uint64_t n_upper_lists);
+void orc_graph_set_features(orc_graph *g, const unsigned char *rows, uint32_t feat_h, uint32_t row_bytes);
+void orc_project_query(const uint16_t *W, uint32_t h, uint32_t hp4, uint32_t d, const float *q, float *gq);
 void orc_graph_info(const orc_graph *g, uint64_t *out /* n,d,ld,M,M0,max_level,entry,n_upper_lists */);
 void orc_graph_export(const orc_graph *g, uint8_t *levels, uint32_t *upper_off, uint32_t *adj0,
                       uint32_t *adjU);
@@ -104,7 +106,7 @@ void orc_hybrid_rerank(const uint64_t *idx, const float *vscore, uint32_t n, con
 
 /* ---- recompute encoder restatement (dense + L2 normalise, bf16 inputs, f32 accumulate) ---------- */
 uint16_t orc_bf16_rne(float f);
-void orc_synth_features(uint64_t seed, uint32_t h, uint32_t n_clusters, float sigma, uint32_t stream,
+void orc_synth_features(uint64_t seed, uint32_t h, uint32_t r_int, uint32_t n_clusters, float sigma, uint32_t stream,
                         uint64_t i0, uint64_t n, uint16_t *out);
 void orc_synth_weights(uint64_t seed, uint32_t h, uint32_t d, uint16_t *out);
 void orc_recompute_encode(const uint16_t *F, uint64_t n, uint32_t h, const uint16_t *W, uint32_t d, float *out);

@@ -57,6 +57,8 @@ def lib():
                                             C.c_uint32, C.c_uint32, C.c_uint32, u8p, u32p, u32p,
                                             u32p, C.c_uint64]
         L.orc_graph_info.argtypes = [C.c_void_p, u64p]
+        L.orc_graph_set_features.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_uint32]
+        L.orc_project_query.argtypes = [C.POINTER(C.c_uint16), C.c_uint32, C.c_uint32, C.c_uint32, f32p, f32p]
         L.orc_graph_export.argtypes = [C.c_void_p, u8p, u32p, u32p, u32p]
         L.orc_graph_free.argtypes = [C.c_void_p]
         L.orc_graph_search.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_int, u64p,
@@ -69,7 +71,7 @@ def lib():
                                         f32p]
         L.orc_l2_normalize.argtypes = [f32p, C.c_uint32]
         u16p = C.POINTER(C.c_uint16)
-        L.orc_synth_features.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64,
+        L.orc_synth_features.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64,
                                          C.c_uint64, u16p]
         L.orc_synth_weights.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, u16p]
         L.orc_recompute_encode.argtypes = [u16p, C.c_uint64, C.c_uint32, u16p, C.c_uint32, f32p]
@@ -147,6 +149,12 @@ class Graph:
                                         _p(adj0, u32p), _p(adjU, u32p), nul)
         return cls(h, X, keep=(levels, upper_off, adj0, adjU))
 
+    def set_features(self, rows_bytes, feat_h, row_bytes):
+        """recompute-on mode: rows_bytes = uint8 [n, row_bytes]; queries must then be projected (project_queries)"""
+        self._feat = np.ascontiguousarray(rows_bytes, np.uint8)
+        lib().orc_graph_set_features(self.h, _p(self._feat, u8p), feat_h, row_bytes)
+        self.d = feat_h
+
     def export(self):
         levels = np.zeros(self.n, np.uint8)
         upper_off = np.zeros(self.n, np.uint32)
@@ -184,9 +192,9 @@ class Graph:
             pass
 
 
-def synth_features(seed, h, n_clusters, sigma, stream, i0, n):
+def synth_features(seed, h, n_clusters, sigma, stream, i0, n, r_int=0):
     out = np.empty((n, h), np.uint16)
-    lib().orc_synth_features(seed, h, n_clusters, sigma, stream, i0, n, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    lib().orc_synth_features(seed, h, r_int, n_clusters, sigma, stream, i0, n, out.ctypes.data_as(C.POINTER(C.c_uint16)))
     return out
 
 
@@ -217,6 +225,15 @@ def recompute_encode_pooled(F, mask, W, L):
     lib().orc_recompute_encode_pooled(F.ctypes.data_as(u16p), _p(m, u8p), n, L, F.shape[1], W.ctypes.data_as(u16p),
                                       W.shape[1], _p(out, f32p))
     return out
+
+
+def project_queries(W, Q, hp4):
+    W = np.ascontiguousarray(W, np.uint16)
+    Q = np.ascontiguousarray(Q, np.float32)
+    G = np.zeros((Q.shape[0], hp4), np.float32)
+    for i in range(Q.shape[0]):
+        lib().orc_project_query(W.ctypes.data_as(C.POINTER(C.c_uint16)), W.shape[0], hp4, W.shape[1], _p(Q[i], f32p), _p(G[i], f32p))
+    return G
 
 
 def merge_topk(keys, dists, counts, k_out):

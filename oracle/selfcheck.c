@@ -30,7 +30,7 @@ int main(void) {
     uint64_t hi[3] = {0, 1, 2}, ho[3]; float hv[3] = {0.9f, 0.8f, 0.7f}, hb[3] = {0.5f, 0.9f, 0.3f}, hs[3];
     orc_hybrid_rerank(hi, hv, 3, hb, 3, 0.5f, ho, hs);
     uint16_t *F = malloc(100 * 32 * 2), *W = malloc(32 * d * 2); float *E = malloc(100 * d * 4);
-    orc_synth_features(1, 32, 8, 1.0f, 0, 0, 100, F); orc_synth_weights(1, 32, d, W); orc_recompute_encode(F, 100, 32, W, d, E);
+    orc_synth_features(1, 32, 8, 8, 1.0f, 0, 0, 100, F); orc_synth_weights(1, 32, d, W); orc_recompute_encode(F, 100, 32, W, d, E);
     orc_graph_free(g); orc_graph_free(g2); orc_graph_free(v);
     free(X); free(Q); free(lv); free(uo); free(a0); free(aU); free(F); free(W); free(E);
     puts("oracle selfcheck OK");

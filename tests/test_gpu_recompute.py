@@ -20,10 +20,13 @@ def _mk(la, po, n, h, d, nq):
     dF, dW = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W)
     # device generators are bit-identical to the oracle's
     gF, gW = la.DeviceArray((n, h), np.uint16), la.DeviceArray((h, d), np.uint16)
-    chk(L.leann_synth_features_device(SEED, h, 64, 1.0, 0, 0, n, gF.ptr, None))
+    chk(L.leann_synth_features_device(SEED, h, 0, 64, 1.0, 0, 0, n, gF.ptr, None))
     chk(L.leann_synth_weights_device(SEED, h, d, gW.ptr, None))
     la.sync()
     assert (gF.to_host() == F).all() and (gW.to_host() == W).all()
+    chk(L.leann_synth_features_device(SEED, h, 16, 64, 1.0, 1, 77, min(n, 500), gF.ptr, None))  # lifted (intrinsic dim 16) variant
+    la.sync()
+    assert (gF.to_host()[:min(n, 500)] == po.synth_features(SEED, h, 64, 1.0, 1, 77, min(n, 500), r_int=16)).all()
     r = C.c_void_p()
     chk(L.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))
     return L, chk, F, W, Q, r, (dF, dW)
@@ -116,4 +119,58 @@ def test_masked_mean_pooling_provider(la, po, gpu, L):
         k0, s0 = po.scan_topk(E, Q[i], k, mode=0)
         assert np.abs(gs[i] - s0).max() <= 1e-5
         assert len(set(gk[i].tolist()) & set(k0.tolist())) >= k - 1
+    Lc.leann_recompute_close(r)
+
+
+def test_recompute_on_graph_search(la, po, gpu):
+    """Graph index with NO stored vectors: distances recomputed from bf16 features, dist = 1 - <f, W q> / ||W^T f||.
+    (a) GPU traversal == oracle traversal over the same bytes, bit for bit; (b) same neighbours as the stored-vector
+    index built from the materialised embeddings (scores within 1e-5); (c) recall vs exact search."""
+    from util import recall_at_k
+    n, h, d, nq, k = 20000, 256, 768, 200, 10
+    Lc, chk = la.lib(), la._native.check
+    F = po.synth_features(SEED, h, 64, 1.0, 0, 0, n)
+    W = po.synth_weights(SEED, h, d)
+    Q = po.recompute_encode(po.synth_features(SEED, h, 64, 1.0, 1, 0, nq), W)
+    dF, dW = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W)
+    r = C.c_void_p()
+    chk(Lc.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))
+    hb = C.c_void_p()
+    chk(Lc.leann_recompute_build_index(r, 0, 16, 64, C.byref(hb)))
+    s = la.BackendSearcher(hb, la.BackendType.Hnsw)
+    fh, rb = C.c_uint32(0), C.c_uint32(0)
+    chk(Lc.leann_backend_feature_rows_export(hb, C.byref(fh), C.byref(rb), None))
+    assert fh.value == 256 and rb.value == 520
+    rows = np.zeros((n, rb.value), np.uint8)
+    chk(Lc.leann_backend_feature_rows_export(hb, None, None, rows.ctypes.data))
+    assert (rows[:, :512].view(np.uint16) == F).all()
+    s.stats(reset=True)
+    gk, gd, gc = s.search_batch(Q, k, 64)
+    st = s.stats()
+    assert st["algorithmic_bytes"] < st["n_dist_evals"] * 600  # 520 B per evaluated neighbour, not 3 072
+    # (a) oracle over the same graph + feature bytes + projected queries
+    g = s.graph_export()
+    Gr = po.Graph.from_arrays(np.zeros((n, 1), np.float32), 16, 32, g["max_level"], g["entry"], g["levels"], g["upper_off"],
+                              g["adj0"], g["adjU"])
+    Gr.set_features(rows, fh.value, rb.value)
+    ok, od, oc, ost = Gr.search_batch(po.project_queries(W, Q, fh.value), k, 64, 0, 8)
+    assert (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    assert st["n_dist_evals"] == int(ost[:, 0].sum())
+    # (b) the stored-vector twin: materialised embeddings, same construction -> same graph, same neighbours
+    E = po.recompute_encode(F, W)
+    dE = la.DeviceArray((n, d), np.float32)
+    chk(Lc.leann_recompute_encode_device(r, 0, n, dE.ptr, None))
+    la.sync()
+    s2 = la.BackendSearcher.build_device(la.BackendType.Hnsw, dE.ptr, n, d, d, 16, 64)
+    g2 = s2.graph_export()
+    assert (g2["adj0"] == g["adj0"]).all()
+    k2, d2, _ = s2.search_batch(Q, k, 64)
+    assert np.abs(d2 - gd).max() <= 1e-5
+    assert (k2 == gk).mean() >= 0.99  # identical except across float near-ties
+    # (c) recall against exact search over the true embeddings
+    assert recall_at_k(gk, po.exact_topk(E, Q, k)) >= 0.93
+    with pytest.raises(la.LeannError, match="no vectors"):
+        s.save("/tmp/x.leann")
+    s2.close()
+    s.close()
     Lc.leann_recompute_close(r)
