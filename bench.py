@@ -400,7 +400,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": ("beam_search_feat_kernel<1,4,4> (+ score_mfma_kernel query projection)" if rgraph else
+            "traffic": traffic, "kernel": ("beam_search_feat_kernel<1,8,4> (+ score_mfma_kernel query projection)" if rgraph else
                        "beam_search_kernel<3,4,4,false>" if ld == 768 else "beam_search_kernel"),
             "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_query": bytes_per_query,
             "algorithmic_bytes_per_launch": bytes_per_launch,

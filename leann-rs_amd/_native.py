@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libleann_hip.so")
+LIB_PATH = os.environ.get("LEANN_LIB") or os.path.join(_HERE, "csrc", "libleann_hip.so")  # LEANN_LIB: diagnostic builds
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)

@@ -233,7 +233,7 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
         a.ldq = h->g.feat_h;
         const int T = (int)((h->g.feat_h + 255) / 256);
         switch (T) {
-            case 1: return launch_search_feat<1, 4>(h->g, a, st);
+            case 1: return launch_search_feat<1, 8>(h->g, a, st);
             case 2: return launch_search_feat<2, 6>(h->g, a, st);
             case 3: case 4: return launch_search_feat<4, 4>(h->g, a, st);
             default: leann_set_error("recompute-on index: feature width %u > 1024 not supported", h->g.feat_h); return LEANN_ERR_INVALID;
@@ -288,6 +288,12 @@ extern "C" int leann_backend_search_batch_device(const leann_backend *hc, const 
     a.out_dists = d_dists;
     a.out_counts = d_counts;
     a.out_stats = d_stats;
+#ifdef LEANN_STAMPS
+    if (const char *e = getenv("LEANN_STAMP_BUF")) { // diagnostic build: [nq x 8] u64 device buffer address in the environment
+        a.out_nexp = reinterpret_cast<uint32_t *>(strtoull(e, nullptr, 0));
+        a.exp_cap = 0xFEED;
+    }
+#endif
     return leann_internal_launch_search(h, a, st);
 }
 

@@ -155,7 +155,7 @@ struct SearchLds {
 };
 __host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits) {
     size_t efp = (ef + 1) & ~1u;
-    size_t b = 2 * efp * 8 + (size_t)maxdeg * 8 + (size_t)maxdeg * 4 + 16 * 4;
+    size_t b = 2 * efp * 8 + ((size_t)maxdeg + 8) * 8 + (size_t)maxdeg * 4 + 16 * 4; // s_key carries 8 sentinel slots
     b = (b + 15) & ~(size_t)15;
     return b + ((size_t)1 << hash_bits) * 4;
 }
@@ -169,9 +169,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     SearchLds s;
     uint64_t *const W0 = reinterpret_cast<uint64_t *>(smem); // buffer b lives at W0 + b*efp (no pointer array: stays out of scratch)
     s.s_key = W0 + 2 * efp;
-    s.s_new = reinterpret_cast<uint32_t *>(s.s_key + maxdeg);
+    s.s_new = reinterpret_cast<uint32_t *>(s.s_key + maxdeg + 8);
     s.misc = s.s_new + maxdeg;
-    size_t off = 2 * (size_t)efp * 8 + (size_t)maxdeg * 12 + 64;
+    size_t off = 2 * (size_t)efp * 8 + ((size_t)maxdeg + 8) * 8 + (size_t)maxdeg * 4 + 64;
     off = (off + 15) & ~(size_t)15;
     uint32_t *table = reinterpret_cast<uint32_t *>(smem + off);
     const uint32_t hbits = a.hash_bits, hsize = 1u << hbits;
@@ -202,6 +202,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         best = make_key(dd[0], g.entry); // every wave computes the same value
     }
 
+#ifdef LEANN_STAMPS
+    uint64_t stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     uint32_t wsize = 0, level_hops = 0;
     int cur = 0;
     bool aborted = false;
@@ -233,6 +236,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         uint32_t hop = 0;
         while (sel != LEANN_EMPTY) {
             uint64_t *Wc = W0 + cur * efp, *Wn = W0 + (cur ^ 1) * efp;
+#ifdef LEANN_STAMPS // diagnostic build only (scripts/stamps.sh): where does a hop spend its cycles?
+            const uint64_t st0 = __builtin_amdgcn_s_memtime();
+#endif
             // ---- phase B: adjacency list through the visited table (wave 0) ------------------
             if (wave == 0) {
                 const uint32_t node = key_id(Wc[sel]);
@@ -256,13 +262,20 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 n_vis += n_new;
                 n_evals += n_new;
                 if (!ovf) { if (lv == 0) hops0++; else hopsU++; }
+                if (lane < 8) s.s_key[n_new + lane] = ~0ull; // sentinels: the merge scans keys 8 at a time
                 if (lane == 0) {
                     s.misc[0] = n_new;
                     s.misc[1 + (hop & 1)] = LEANN_EMPTY; // slot THIS hop's merge mins into (last read two hops ago)
                     if (ovf) s.misc[3] = 1;
                 }
             }
+#ifdef LEANN_STAMPS
+            const uint64_t stB = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads(); // B1
+#ifdef LEANN_STAMPS
+            const uint64_t stB1 = __builtin_amdgcn_s_memtime();
+#endif
             const uint32_t table_full = s.misc[3];
             if (table_full) {
                 if (hbm) { aborted = true; break; } // even the 2^16-slot HBM table is 75 % full
@@ -311,35 +324,65 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                         if (r < nrows) s.s_key[j0 + r * NW] = make_key(dd[r], ids[r]);
                 }
             }
+#ifdef LEANN_STAMPS
+            const uint64_t stC = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads(); // B2
+#ifdef LEANN_STAMPS
+            const uint64_t stB2 = __builtin_amdgcn_s_memtime();
+#endif
             // ---- phase D: merge by rank into the other buffer; pick the next candidate ----------
+            // One work item per old entry (rank = index + #new keys below it) and per new key (rank = #old below it, by
+            // binary search, + #new below it); the scan over the new keys reads 16 B per LDS instruction, 8 keys per
+            // unrolled step, so the loads pipeline instead of paying one LDS latency per key.
             uint32_t *next_slot = &s.misc[1 + (hop & 1)];
-            for (uint32_t t = tid; t < wsize; t += NW * 64) {
-                uint64_t k = Wc[t];
-                if (t == sel) k |= 1ull;
+            const uint32_t n_pad = (n_new + 7) & ~7u;
+            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(s.s_key);
+            for (uint32_t it = tid; it < ((wsize + n_new + 63) & ~63u); it += NW * 64) { // whole waves: wave_min below
+                const bool valid = it < wsize + n_new, isW = it < wsize;
+                uint64_t k = !valid ? ~0ull : (isW ? Wc[it] : s.s_key[it - wsize]);
+                if (isW && it == sel) k |= 1ull;
+                const uint64_t kk = k >> 1;
                 uint32_t cnt = 0;
-                for (uint32_t j = 0; j < n_new; j++) cnt += (s.s_key[j] >> 1) < (k >> 1);
-                uint32_t rank = t + cnt;
-                if (rank < ef_l) {
+#pragma unroll 4
+                for (uint32_t j = 0; j < n_pad; j += 2) {
+                    const ulonglong2 v = kp[j >> 1];
+                    cnt += ((v.x >> 1) < kk) + ((v.y >> 1) < kk);
+                }
+                uint32_t rank = isW ? it + cnt : cnt;
+                if (valid && !isW) {
+                    uint32_t lo = 0, hi = wsize;
+                    while (lo < hi) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        if ((Wc[mid] >> 1) < kk) lo = mid + 1; else hi = mid;
+                    }
+                    rank += lo;
+                }
+                uint32_t cand = LEANN_EMPTY;
+                if (valid && rank < ef_l) {
                     Wn[rank] = k;
-                    if (!(k & 1ull)) atomicMin(next_slot, rank);
+                    if (!(k & 1ull)) cand = rank;
                 }
+                // first unexpanded entry of the new list: wave-level min, one LDS atomic per wave
+                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 1, 64));
+                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 2, 64));
+                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 4, 64));
+                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 8, 64));
+                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 16, 64));
+                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 32, 64));
+                if (lane == 0 && cand != LEANN_EMPTY) atomicMin(next_slot, cand);
             }
-            for (uint32_t j = tid; j < n_new; j += NW * 64) {
-                uint64_t k = s.s_key[j];
-                uint32_t lo = 0, hi = wsize;
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if ((Wc[mid] >> 1) < (k >> 1)) lo = mid + 1; else hi = mid;
-                }
-                uint32_t cnt = lo;
-                for (uint32_t jj = 0; jj < n_new; jj++) cnt += s.s_key[jj] < k;
-                if (cnt < ef_l) {
-                    Wn[cnt] = k;
-                    atomicMin(next_slot, cnt);
-                }
-            }
+#ifdef LEANN_STAMPS
+            const uint64_t stD = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads(); // B3
+#ifdef LEANN_STAMPS
+            {
+                const uint64_t stE = __builtin_amdgcn_s_memtime();
+                stamp[0] += stB - st0; stamp[1] += stB1 - stB; stamp[2] += stC - stB1; stamp[3] += stB2 - stC;
+                stamp[4] += stD - stB2; stamp[5] += stE - stD; stamp[6] += 1;
+            }
+#endif
             sel = *next_slot;
             wsize = min(wsize + n_new, ef_l);
             cur ^= 1;
@@ -383,9 +426,15 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
             a.out_dists[o] = __uint_as_float(0x7F800000u);
         }
     }
+#ifdef LEANN_STAMPS
+    if (tid == 0 && a.out_expanded == nullptr && a.exp_cap == 0xFEED) { // stamps go to a buffer of their own (passed via out_nexp)
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.out_nexp) + (size_t)qi * 8;
+        for (int i = 0; i < 7; i++) dst[i] = stamp[i];
+    }
+#endif
     if (tid == 0) {
         a.out_counts[qi] = nout;
-        if (a.out_nexp) a.out_nexp[qi] = min(level_hops, a.exp_cap);
+        if (a.out_nexp && a.exp_cap != 0xFEED) a.out_nexp[qi] = min(level_hops, a.exp_cap);
         if (a.out_stats) {
             a.out_stats[(size_t)qi * 4 + 0] = n_evals;
             a.out_stats[(size_t)qi * 4 + 1] = hops0;
