@@ -37,6 +37,7 @@ WORKLOADS = {
     # efc = 128 graph (905 k QPS), ef = 56 on efc = 200 (1.08 M QPS, build 31 s), ef = 48 on efc = 320 (1.15 M, build 50 s)
     "hnsw10m": dict(rows=10_000_000, d=768, M=32, efc=200, ef=128),
     "hnsw1m": dict(rows=1_000_000, d=768, M=32, efc=128, ef=128),     # BASELINE configs[1]
+    "hnsw100m_shard8": dict(rows=12_500_000, d=768, M=32, efc=200, ef=128),  # BASELINE configs[3]: 100M x 768 = 8 shards of 12.5M (--gpus 8)
     "hnsw100k": dict(rows=100_000, d=768, M=32, efc=128, ef=128),     # quick check
     # configs[4] search leg: DiskANN/Vamana, 1536-d.  R = 64 (R = 32 reaches recall 0.98 at 1M but only 0.81 at 5M)
     "vamana10m1536": dict(rows=10_000_000, d=1536, M=64, efc=128, ef=128, backend=1),

@@ -82,7 +82,15 @@ __device__ __forceinline__ void fma4(float4 &acc, const float4 &a, const float4 
 // Load lane's float4 of chunk t from a 16-byte aligned, zero-padded row of leading dimension ld.
 __device__ __forceinline__ float4 row_load4(const float *__restrict__ row, uint32_t ld, int t, int lane) {
     uint32_t j = 256u * t + 4u * lane;
+#ifdef LEANN_NT_ROWS
+    if (j < ld) { // experiment (scripts/variant.sh): streamed rows bypass-ish the caches
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(row + j));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+#else
     if (j < ld) return *reinterpret_cast<const float4 *>(row + j);
+#endif
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 // Guarded scalar loads (query rows may be unaligned / unpadded: leading dimension = d).
