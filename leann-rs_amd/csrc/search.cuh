@@ -7,11 +7,14 @@
 // Mapping: one workgroup (NW waves of 64) per query.
 //   * query vector: registers of every wave (lane l holds elements 256t+4l..+3), loaded once;
 //   * result/candidate beam W: sorted u64 keys in LDS, double buffered, merged by rank;
-//   * visited set: open-addressing hash table in LDS (global memory in the overflow re-run);
+//   * visited set: open-addressing hash table in LDS; a query that outgrows it migrates, mid-search, to a pooled
+//     table in HBM (generation-tagged slots touched only by atomics) and continues;
 //   * per hop: wave 0 reads the adjacency list (one neighbour id per lane) and filters it through
 //     the visited table; the not-yet-seen rows are dealt round-robin to the NW waves, each wave
 //     streams a whole row per instruction group (64 lanes x 16 B = 1 KiB coalesced), R rows in
 //     flight, and reduces with the canonical wave tree (common.cuh);
+//   * merge: one work item per old / new entry ranks itself against the new keys with pipelined 16-byte LDS scans
+//     and scatters into the other W buffer; a wave-level min picks the next candidate;
 //   * exactly one candidate is expanded per step, in the same order as the sequential algorithm,
 //     so ids AND distances are bit-identical to the oracle.
 #pragma once
@@ -151,7 +154,6 @@ struct SearchLds {
     uint64_t *s_key;
     uint32_t *s_new;
     uint32_t *misc;  // [0]=n_new [1],[2]=next selection (double buffered) [3]=table full [4]=pool slot [5]=generation
-    uint32_t *table; // LDS table (nullptr for the global variant)
 };
 __host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits) {
     size_t efp = (ef + 1) & ~1u;
