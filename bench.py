@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=16384)
+    ap.add_argument("--filter-selectivity", type=float, default=0.0,
+                    help="side experiment (not the headline metric): metadata-filtered search with a seeded random allow-bitmap "
+                         "of this density evaluated inside the traversal; recall is measured against the exact FILTERED top-k")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,14 +279,29 @@ def main():
     stats = torch.zeros((n_pool, B, 4), dtype=torch.int32, device=dev)
     stream.synchronize()
 
+    allow = None
+    if args.filter_selectivity > 0:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x5EED0004 + rank)
+        bits = torch.zeros(((rows + 7) // 8) * 8, dtype=torch.uint8, device=dev)
+        bits[:rows] = (torch.rand(rows, device=dev, generator=gen) < args.filter_selectivity).to(torch.uint8)
+        wts = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
+        allow = (bits.view(-1, 8) * wts).sum(1, dtype=torch.int32).to(torch.uint8).contiguous()  # bit i&7 of byte i>>3
+        del bits
+        torch.cuda.synchronize()
+
     def search(step, timed_events=None):
         """one step of the hot path on `stream`"""
         qb = step % n_pool
         qptr = Q.data_ptr() + qb * B * ld * 4
         if timed_events is not None:
             timed_events[0].record(stream)
-        searcher.search_batch_device(qptr, B, k, ef, keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
-                                     stats.data_ptr() + qb * B * 16, sp)
+        if allow is not None:
+            searcher.search_filtered_batch_device(qptr, B, k, ef, allow.data_ptr(), 0, keys.data_ptr(), dists.data_ptr(),
+                                                  counts.data_ptr(), stats.data_ptr() + qb * B * 16, sp)
+        else:
+            searcher.search_batch_device(qptr, B, k, ef, keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
+                                         stats.data_ptr() + qb * B * 16, sp)
         if timed_events is not None:
             timed_events[1].record(stream)
         if shard:
@@ -301,10 +319,10 @@ def main():
     gt_c = torch.empty((nrq,), dtype=torch.int32, device=dev)
     t0 = time.time()
     if rgraph:  # exact truth = the brute-force recompute search (fused MFMA kernel) over the same encoder
-        chk(L.leann_recompute_search_batch_device(rc_h, Q.data_ptr(), nrq, k, None, gt_k.data_ptr(), gt_s.data_ptr(),
+        chk(L.leann_recompute_search_batch_device(rc_h, Q.data_ptr(), nrq, k, allow.data_ptr() if allow is not None else None, gt_k.data_ptr(), gt_s.data_ptr(),
                                                   gt_c.data_ptr(), sp))
     else:
-        chk(L.leann_scan_topk_device(X.data_ptr(), rows, d, ld, Q.data_ptr(), nrq, k, None, row0, gt_k.data_ptr(),
+        chk(L.leann_scan_topk_device(X.data_ptr(), rows, d, ld, Q.data_ptr(), nrq, k, allow.data_ptr() if allow is not None else None, row0, gt_k.data_ptr(),
                                      gt_s.data_ptr(), gt_c.data_ptr(), sp))
     stream.synchronize()
     if shard:  # global truth = merge of per-shard exact lists (scores descending)
@@ -369,7 +387,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))  # measured with rocprofv3 --pmc on this exact command (profiles/*.md); only valid for the same beam
-            traffic = tj.get("hbm_bytes_per_launch") if tj.get("ef_search") == ef and B == 16384 and k == 10 else None
+            traffic = tj.get("hbm_bytes_per_launch") if tj.get("ef_search") == ef and B == 16384 and k == 10 and allow is None else None
         except Exception:
             traffic = None
 
@@ -398,10 +416,14 @@ def main():
             "ef_search": ef, "top_k": k, "batch": B,
             "parallelism": ("single" if world == 1 else (f"shard{world}+rccl_allgather" if shard else f"replica{world}")),
             "index_build_s": build_s,
+            **({"filter_selectivity": args.filter_selectivity,
+                "filter_note": "side experiment: allow-bitmap evaluated inside the traversal; recall vs the exact filtered top-k"}
+               if allow is not None else {}),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": ("beam_search_feat_kernel<1,8,4> (+ score_mfma_kernel query projection)" if rgraph else
+            "traffic": traffic, "kernel": ("beam_search_filtered_kernel" if allow is not None else
+                       "beam_search_feat_kernel<1,8,4> (+ score_mfma_kernel query projection)" if rgraph else
                        "beam_search_kernel<3,4,4,false>" if ld == 768 else "beam_search_kernel"),
             "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_query": bytes_per_query,
             "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -415,7 +437,7 @@ def main():
                                             f"{rows}-row shard); end_to_end_qps = value / n_gpus over the {corpus_total}-row corpus")
 
     # ---- CPU baseline: the oracle (C restatement) walking the SAME graph on the host cores --------
-    if world == 1 and not args.no_cpu_baseline and rank == 0:
+    if world == 1 and not args.no_cpu_baseline and rank == 0 and allow is None:
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po

@@ -61,6 +61,21 @@ int leann_backend_search_batch(const leann_backend *h, const float *queries, siz
                                size_t top_k, size_t complexity, uint64_t *keys, float *dists,
                                uint32_t *counts);
 
+/* Additive: metadata-filtered search with the filter evaluated INSIDE the traversal,
+ * replacing IndexSearcher's fetch_k = 5*top_k over-fetch + post-filter (src/index/searcher.rs:129-133,:190-194).
+ * `allow` is a bitmap over positions (bit i&7 of byte i>>3 set = position i may be returned; positions are local to
+ * the handle, i.e. key - key_offset), ceil(len/8) bytes; in the batch call query i uses allow + i*allow_stride
+ * (allow_stride == 0: one bitmap for the whole batch).  The graph is walked exactly as by the unfiltered search
+ * (disallowed nodes still route); the answer is the top_k best allowed positions among EVERY node whose distance
+ * the level-0 walk evaluated (~30x the beam), best first.  allow == NULL: the unfiltered search. */
+int leann_backend_search_filtered(const leann_backend *h, const float *query, size_t top_k,
+                                  size_t complexity, const uint8_t *allow, uint64_t *keys,
+                                  float *dists, size_t *n_out);
+int leann_backend_search_filtered_batch(const leann_backend *h, const float *queries, size_t nq,
+                                        size_t top_k, size_t complexity, const uint8_t *allow,
+                                        size_t allow_stride, uint64_t *keys, float *dists,
+                                        uint32_t *counts);
+
 /* Additive: request coalescing for servers that call leann_backend_search from many threads (one query per
  * call, src/cli/serve.rs:289-292).  Concurrent callers are gathered for up to wait_us microseconds (or
  * max_batch queries) and answered by one batched launch; results are identical.  (0, 0) disables. */
@@ -126,6 +141,12 @@ int leann_backend_search_batch_device(const leann_backend *h, const float *d_que
                                       size_t top_k, size_t complexity, uint64_t *d_keys,
                                       float *d_dists, uint32_t *d_counts, uint32_t *d_stats,
                                       void *stream);
+/* ... with a device-resident allow-bitmap (see leann_backend_search_filtered) */
+int leann_backend_search_filtered_batch_device(const leann_backend *h, const float *d_queries,
+                                               size_t nq, size_t top_k, size_t complexity,
+                                               const uint8_t *d_allow, size_t allow_stride,
+                                               uint64_t *d_keys, float *d_dists, uint32_t *d_counts,
+                                               uint32_t *d_stats, void *stream);
 /* device pointer of the rows (for ground-truth scans) */
 const float *leann_backend_device_rows(const leann_backend *h);
 

@@ -35,6 +35,9 @@ SIGNATURES = {
     "leann_backend_open": (C.c_int, [C.c_char_p, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(vp)]),
     "leann_backend_search": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, u64p, f32p, C.POINTER(C.c_size_t)]),
     "leann_backend_search_batch": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p, u32p]),
+    "leann_backend_search_filtered": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, u8p, u64p, f32p, C.POINTER(C.c_size_t)]),
+    "leann_backend_search_filtered_batch": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u8p, C.c_size_t,
+                                                     u64p, f32p, u32p]),
     "leann_backend_set_coalescing": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
     "leann_backend_coalescing_stats": (C.c_int, [vp, u64p, u64p]),
     "leann_backend_len": (C.c_size_t, [vp]),
@@ -53,6 +56,8 @@ SIGNATURES = {
     "leann_backend_save": (C.c_int, [vp, C.c_char_p]),
     "leann_backend_search_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, vp, vp,
                                                    vp, vp]),
+    "leann_backend_search_filtered_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t,
+                                                            vp, vp, vp, vp, vp]),
     "leann_backend_device_rows": (vp, [vp]),
     "leann_synth_rows_device": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_float, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),

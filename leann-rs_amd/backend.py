@@ -101,10 +101,48 @@ class BackendSearcher:
                                                    _p(keys, u64p), _p(dists, f32p), _p(counts, u32p)))
         return keys, dists, counts
 
+    def search_filtered(self, query, top_k, complexity, allow):
+        """search restricted to the positions whose bit is set in `allow` (uint8 bitmap, ceil(len/8) bytes);
+        the filter runs inside the traversal (replaces searcher.rs:129-133 over-fetch)."""
+        q = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if q.shape[0] != self.dims():
+            raise LeannError(1, f"query has {q.shape[0]} dimensions, index has {self.dims()}")
+        allow = np.ascontiguousarray(allow, np.uint8).reshape(-1)
+        if allow.shape[0] < (self.len() + 7) // 8:
+            raise LeannError(1, f"allow-bitmap has {allow.shape[0]} bytes, index needs {(self.len() + 7) // 8}")
+        keys = np.zeros(max(top_k, 1), np.uint64)
+        dists = np.zeros(max(top_k, 1), np.float32)
+        n = C.c_size_t(0)
+        N.check(N.lib().leann_backend_search_filtered(self._h, _p(q, f32p), top_k, complexity, _p(allow, u8p),
+                                                      _p(keys, u64p), _p(dists, f32p), C.byref(n)))
+        return keys[: n.value].copy(), dists[: n.value].copy()
+
+    def search_filtered_batch(self, queries, top_k, complexity, allow):
+        """allow: [ceil(len/8)] shared bitmap or [nq, stride] one bitmap per query"""
+        Q = np.ascontiguousarray(queries, np.float32)
+        if Q.ndim != 2 or Q.shape[1] != self.dims():
+            raise LeannError(1, f"queries must be [nq x {self.dims()}]")
+        allow = np.ascontiguousarray(allow, np.uint8)
+        stride = 0 if allow.ndim == 1 else allow.shape[1]
+        if allow.shape[-1] < (self.len() + 7) // 8 or (allow.ndim == 2 and allow.shape[0] != Q.shape[0]):
+            raise LeannError(1, "allow-bitmap shape does not match the index / the batch")
+        nq = Q.shape[0]
+        keys = np.full((nq, top_k), np.iinfo(np.uint64).max, np.uint64)
+        dists = np.full((nq, top_k), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        N.check(N.lib().leann_backend_search_filtered_batch(self._h, _p(Q, f32p), nq, top_k, complexity, _p(allow, u8p),
+                                                            stride, _p(keys, u64p), _p(dists, f32p), _p(counts, u32p)))
+        return keys, dists, counts
+
     def search_batch_device(self, d_queries, nq, top_k, complexity, d_keys, d_dists, d_counts,
                             d_stats=None, stream=None):
         N.check(N.lib().leann_backend_search_batch_device(self._h, d_queries, nq, top_k, complexity,
                                                           d_keys, d_dists, d_counts, d_stats, stream))
+
+    def search_filtered_batch_device(self, d_queries, nq, top_k, complexity, d_allow, allow_stride, d_keys, d_dists,
+                                     d_counts, d_stats=None, stream=None):
+        N.check(N.lib().leann_backend_search_filtered_batch_device(self._h, d_queries, nq, top_k, complexity, d_allow,
+                                                                   allow_stride, d_keys, d_dists, d_counts, d_stats, stream))
 
     def set_coalescing(self, wait_us=200, max_batch=4096):
         """gather concurrent single-query search() callers into one batched launch ((0, 0) disables)"""

@@ -69,6 +69,7 @@ static void ws_free(Workspace *w) {
     (void)hipFree(w->d_dists);
     (void)hipFree(w->d_counts);
     (void)hipFree(w->d_stats);
+    (void)hipFree(w->d_allow);
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }
@@ -138,27 +139,30 @@ static uint32_t pick_hash_bits(uint32_t ef) {
     return b;
 }
 
-template <int T, int R, int NW>
-static int launch_search_NW(const GraphView &g, const SearchArgs &a, hipStream_t st) {
-    const uint32_t maxdeg = std::max(g.M0, g.M);
-    size_t lds = search_lds_bytes(a.ef, maxdeg, a.hash_bits);
-    if (lds > 160 * 1024) {
-        leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, lds);
-        return LEANN_ERR_INVALID;
-    }
-    if (a.q_rows) {
-        if (lds > 64 * 1024)
-            HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_kernel<T, R, NW, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((beam_search_kernel<T, R, NW, true>), dim3(a.nq), dim3(NW * 64), lds, st, g, a);
-    } else {
-        if (lds > 64 * 1024)
-            HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_kernel<T, R, NW, false>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((beam_search_kernel<T, R, NW, false>), dim3(a.nq), dim3(NW * 64), lds, st, g, a);
-    }
+template <typename K>
+static int launch_one(K kernel, int nthreads, size_t lds, const GraphView &g, const SearchArgs &a, hipStream_t st) {
+    if (lds > 64 * 1024)
+        HIP_CHECK_RET(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kernel, dim3(a.nq), dim3(nthreads), lds, st, g, a);
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
+}
+static int search_lds_checked(const GraphView &g, const SearchArgs &a, size_t *lds) {
+    *lds = search_lds_bytes(a.ef, std::max(g.M0, g.M), a.hash_bits, a.allow ? a.k : 0u);
+    if (*lds > 160 * 1024) {
+        leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, *lds);
+        return LEANN_ERR_INVALID;
+    }
+    return LEANN_OK;
+}
+
+template <int T, int R, int NW>
+static int launch_search_NW(const GraphView &g, const SearchArgs &a, hipStream_t st) {
+    size_t lds;
+    if (int rc = search_lds_checked(g, a, &lds)) return rc;
+    if (a.allow) return launch_one(beam_search_filtered_kernel<T, R, NW>, NW * 64, lds, g, a, st);
+    if (a.q_rows) return launch_one(beam_search_kernel<T, R, NW, true>, NW * 64, lds, g, a, st);
+    return launch_one(beam_search_kernel<T, R, NW, false>, NW * 64, lds, g, a, st);
 }
 
 // Waves per query: 4 for throughput batches (4 workgroups per CU hide each other's dependent hops);
@@ -175,23 +179,14 @@ static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t 
 
 template <int T, int R>
 static int launch_search_feat(const GraphView &g, const SearchArgs &a, hipStream_t st) {
-    const uint32_t maxdeg = std::max(g.M0, g.M);
-    size_t lds = search_lds_bytes(a.ef, maxdeg, a.hash_bits);
-    if (lds > 160 * 1024) {
-        leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, lds);
-        return LEANN_ERR_INVALID;
-    }
+    size_t lds;
+    if (int rc = search_lds_checked(g, a, &lds)) return rc;
     if (a.nq <= 512) {
-        if (lds > 64 * 1024)
-            HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_feat_kernel<T, R, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((beam_search_feat_kernel<T, R, 16>), dim3(a.nq), dim3(16 * 64), lds, st, g, a);
-    } else {
-        if (lds > 64 * 1024)
-            HIP_CHECK_RET(hipFuncSetAttribute((const void *)beam_search_feat_kernel<T, R, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((beam_search_feat_kernel<T, R, 4>), dim3(a.nq), dim3(4 * 64), lds, st, g, a);
+        if (a.allow) return launch_one(beam_search_feat_filtered_kernel<T, R, 16>, 16 * 64, lds, g, a, st);
+        return launch_one(beam_search_feat_kernel<T, R, 16>, 16 * 64, lds, g, a, st);
     }
-    HIP_CHECK_RET(hipGetLastError());
-    return LEANN_OK;
+    if (a.allow) return launch_one(beam_search_feat_filtered_kernel<T, R, 4>, 4 * 64, lds, g, a, st);
+    return launch_one(beam_search_feat_kernel<T, R, 4>, 4 * 64, lds, g, a, st);
 }
 
 // recompute-on mode: queries [nq x dims] -> g = W q [nq x feat_h] into the stream's scratch (f32 MFMA, k-ordered chains)
@@ -264,9 +259,23 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
 extern "C" int leann_backend_search_batch_device(const leann_backend *hc, const float *d_queries, size_t nq,
                                                  size_t top_k, size_t complexity, uint64_t *d_keys, float *d_dists,
                                                  uint32_t *d_counts, uint32_t *d_stats, void *stream) {
+    return leann_backend_search_filtered_batch_device(hc, d_queries, nq, top_k, complexity, nullptr, 0, d_keys, d_dists,
+                                                      d_counts, d_stats, stream);
+}
+
+// Filtered traversal: the allow-bitmap is evaluated inside the kernel instead of the
+// reference's fetch_k = 5*top_k over-fetch + post-filter (src/index/searcher.rs:129-133,:190-194).
+extern "C" int leann_backend_search_filtered_batch_device(const leann_backend *hc, const float *d_queries, size_t nq,
+                                                          size_t top_k, size_t complexity, const uint8_t *d_allow,
+                                                          size_t allow_stride, uint64_t *d_keys, float *d_dists,
+                                                          uint32_t *d_counts, uint32_t *d_stats, void *stream) {
     leann_backend *h = const_cast<leann_backend *>(hc);
     if (!h || !d_queries || !d_keys || !d_dists || !d_counts || top_k == 0) {
         leann_set_error("leann_backend_search_batch_device: null/zero argument");
+        return LEANN_ERR_INVALID;
+    }
+    if (d_allow && allow_stride && allow_stride < (h->g.n + 7) / 8) {
+        leann_set_error("filtered search: allow_stride %zu is smaller than the %zu-byte bitmap", allow_stride, (size_t)(h->g.n + 7) / 8);
         return LEANN_ERR_INVALID;
     }
     if (nq == 0) return LEANN_OK;
@@ -288,6 +297,8 @@ extern "C" int leann_backend_search_batch_device(const leann_backend *hc, const 
     a.out_dists = d_dists;
     a.out_counts = d_counts;
     a.out_stats = d_stats;
+    a.allow = d_allow;
+    a.allow_stride = allow_stride;
 #ifdef LEANN_STAMPS
     if (const char *e = getenv("LEANN_STAMP_BUF")) { // diagnostic build: [nq x 8] u64 device buffer address in the environment
         a.out_nexp = reinterpret_cast<uint32_t *>(strtoull(e, nullptr, 0));
@@ -300,6 +311,13 @@ extern "C" int leann_backend_search_batch_device(const leann_backend *hc, const 
 // BackendSearcher::search batched over host pointers.
 extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k,
                                           size_t complexity, uint64_t *keys, float *dists, uint32_t *counts) {
+    return leann_backend_search_filtered_batch(hc, queries, nq, top_k, complexity, nullptr, 0, keys, dists, counts);
+}
+
+// ... with an optional allow-bitmap over positions (host memory; one shared bitmap when allow_stride == 0)
+extern "C" int leann_backend_search_filtered_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k,
+                                                   size_t complexity, const uint8_t *allow, size_t allow_stride,
+                                                   uint64_t *keys, float *dists, uint32_t *counts) {
     leann_backend *h = const_cast<leann_backend *>(hc);
     if (!h || !queries || !keys || !dists || !counts) {
         leann_set_error("leann_backend_search_batch: null argument");
@@ -342,6 +360,21 @@ extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *
         grow((void **)&w->d_stats, w->cap_stats, nq * 4, 4))
         return fail(LEANN_ERR_DEVICE);
     hipStream_t st = w->stream;
+    if (allow) {
+        const size_t nbytes = (h->g.n + 7) / 8;
+        if (allow_stride && allow_stride < nbytes) {
+            leann_set_error("filtered search: allow_stride %zu is smaller than the %zu-byte bitmap", allow_stride, nbytes);
+            return fail(LEANN_ERR_INVALID);
+        }
+        const size_t total = allow_stride ? allow_stride * nq : nbytes;
+        void *pa = w->d_allow;
+        if (grow(&pa, w->cap_allow, total, 1)) { w->d_allow = (uint8_t *)pa; return fail(LEANN_ERR_DEVICE); }
+        w->d_allow = (uint8_t *)pa;
+        if (hipMemcpyAsync(w->d_allow, allow, total, hipMemcpyHostToDevice, st) != hipSuccess) {
+            leann_set_error("H2D copy of the allow-bitmap failed");
+            return fail(LEANN_ERR_DEVICE);
+        }
+    }
     if (hipMemcpyAsync(w->d_q, queries, qf * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
         leann_set_error("H2D copy of queries failed");
         return fail(LEANN_ERR_DEVICE);
@@ -357,6 +390,8 @@ extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *
     a.out_dists = w->d_dists;
     a.out_counts = w->d_counts;
     a.out_stats = w->d_stats;
+    a.allow = allow ? w->d_allow : nullptr;
+    a.allow_stride = allow_stride;
     rc = leann_internal_launch_search(h, a, st);
     if (rc) return fail(rc);
     std::vector<uint32_t> hstats(nq * 4);
@@ -497,6 +532,18 @@ extern "C" int leann_backend_search(const leann_backend *hc, const float *query,
     }
     uint32_t cnt = 0;
     int rc = leann_backend_search_batch(h, query, 1, top_k, complexity, keys, dists, &cnt);
+    *n_out = cnt;
+    return rc;
+}
+
+// One filtered query (host bitmap of ceil(len/8) bytes, uploaded with the call; callers with a recurring filter keep the
+// bitmap in HBM and use the *_device entry point).  Not coalesced.
+extern "C" int leann_backend_search_filtered(const leann_backend *hc, const float *query, size_t top_k, size_t complexity,
+                                             const uint8_t *allow, uint64_t *keys, float *dists, size_t *n_out) {
+    if (!n_out) { leann_set_error("leann_backend_search_filtered: n_out is null"); return LEANN_ERR_INVALID; }
+    if (!allow) return leann_backend_search(hc, query, top_k, complexity, keys, dists, n_out);
+    uint32_t cnt = 0;
+    int rc = leann_backend_search_filtered_batch(hc, query, 1, top_k, complexity, allow, 0, keys, dists, &cnt);
     *n_out = cnt;
     return rc;
 }

@@ -12,7 +12,8 @@ struct Workspace { // staging of the host-pointer API; one per concurrent caller
     uint64_t *d_keys = nullptr;
     float *d_dists = nullptr;
     uint32_t *d_counts = nullptr, *d_stats = nullptr;
-    size_t cap_q = 0, cap_keys = 0, cap_dists = 0, cap_counts = 0, cap_stats = 0;
+    uint8_t *d_allow = nullptr; // filtered searches: staged allow-bitmap(s)
+    size_t cap_q = 0, cap_keys = 0, cap_dists = 0, cap_counts = 0, cap_stats = 0, cap_allow = 0;
     hipStream_t stream = nullptr;
 };
 

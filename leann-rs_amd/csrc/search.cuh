@@ -15,6 +15,9 @@
 //     flight, and reduces with the canonical wave tree (common.cuh);
 //   * merge: one work item per old / new entry ranks itself against the new keys with pipelined 16-byte LDS scans
 //     and scatters into the other W buffer; a wave-level min picks the next candidate;
+//   * filtered search (allow-bitmap): same traversal; a second sorted list R in LDS keeps the k best
+//     ALLOWED keys among everything evaluated on the target level (top-k of a set: order independent, so again
+//     bit-identical to the oracle's collect-sort-truncate);
 //   * exactly one candidate is expanded per step, in the same order as the sequential algorithm,
 //     so ids AND distances are bit-identical to the oracle.
 #pragma once
@@ -56,6 +59,8 @@ struct SearchArgs {
     unsigned long long *gpool; // [GPOOL_TABLES << GPOOL_BITS]
     uint32_t *gpool_lock;     // [GPOOL_TABLES] 0 = free
     uint32_t *gpool_ctr;      // [0] acquire ticket, [1] generation counter
+    const uint8_t *allow;     // filtered kernels only: bitmap over local positions (bit i of byte i >> 3) ...
+    uint64_t allow_stride;    // ... of query i at allow + i * allow_stride (0: one bitmap shared by the batch)
 };
 
 __device__ __forceinline__ uint32_t vis_hash(uint32_t id, uint32_t bits) {
@@ -149,20 +154,23 @@ __device__ __forceinline__ void wave_dist_rows_feat(const float4 (&q)[T], const 
     }
 }
 
-// LDS carve-up (dynamic): [W0 | W1 | s_key | s_new | misc | table]
+// LDS carve-up (dynamic): [W0 | W1 | s_key | s_new | misc | (filtered: R0 | R1 | s_keyR) | table]
 struct SearchLds {
     uint64_t *s_key;
     uint32_t *s_new;
     uint32_t *misc;  // [0]=n_new [1],[2]=next selection (double buffered) [3]=table full [4]=pool slot [5]=generation
+                     // [6]=1 if the target level's seed is allowed (filtered)
 };
-__host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits) {
+// kf = result-list length of a filtered search (0: unfiltered)
+__host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits, uint32_t kf = 0) {
     size_t efp = (ef + 1) & ~1u;
     size_t b = 2 * efp * 8 + ((size_t)maxdeg + 8) * 8 + (size_t)maxdeg * 4 + 16 * 4; // s_key carries 8 sentinel slots
     b = (b + 15) & ~(size_t)15;
+    if (kf) b += 2 * (size_t)((kf + 1) & ~1u) * 8 + ((size_t)maxdeg + 8) * 8;
     return b + ((size_t)1 << hash_bits) * 4;
 }
 
-template <int T, int R, int NW, bool FEAT>
+template <int T, int R, int NW, bool FEAT, bool FILT = false>
 __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_t qi, unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ef = a.ef;
@@ -175,6 +183,14 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     s.misc = s.s_new + maxdeg;
     size_t off = 2 * (size_t)efp * 8 + ((size_t)maxdeg + 8) * 8 + (size_t)maxdeg * 4 + 64;
     off = (off + 15) & ~(size_t)15;
+    // filtered: R list (k best allowed keys so far, double buffered) + the new keys with disallowed ones blanked
+    const uint32_t kf = FILT ? a.k : 0u, kfp = (kf + 1) & ~1u;
+    uint64_t *const R0 = reinterpret_cast<uint64_t *>(smem + off);
+    uint64_t *const s_keyR = R0 + 2 * kfp;
+    const uint8_t *const allow = FILT ? a.allow + (size_t)qi * a.allow_stride : nullptr;
+    uint32_t rsize = 0;
+    int rcur = 0;
+    if (FILT) off += 2 * (size_t)kfp * 8 + ((size_t)maxdeg + 8) * 8;
     uint32_t *table = reinterpret_cast<uint32_t *>(smem + off);
     const uint32_t hbits = a.hash_bits, hsize = 1u << hbits;
     uint32_t vis_limit = hsize - (hsize >> 2); // 75 % load
@@ -228,9 +244,17 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
             s.misc[1] = LEANN_EMPTY;
             s.misc[2] = LEANN_EMPTY;
             s.misc[3] = 0;
+            if (FILT && lv == (int)a.target_level) {
+                const uint32_t e = key_id(best);
+                const uint32_t ok = (allow[e >> 3] >> (e & 7)) & 1u;
+                if (ok) R0[0] = best;
+                s.misc[6] = ok;
+            }
         }
         __syncthreads();
         if (hbm) gen = s.misc[5];
+        const bool filt_level = FILT && lv == (int)a.target_level;
+        if (filt_level) { rsize = s.misc[6]; rcur = 0; }
         cur = 0;
         wsize = 1;
         n_vis = 1;
@@ -265,6 +289,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 n_evals += n_new;
                 if (!ovf) { if (lv == 0) hops0++; else hopsU++; }
                 if (lane < 8) s.s_key[n_new + lane] = ~0ull; // sentinels: the merge scans keys 8 at a time
+                if (filt_level && lane < 8) s_keyR[n_new + lane] = ~0ull;
                 if (lane == 0) {
                     s.misc[0] = n_new;
                     s.misc[1 + (hop & 1)] = LEANN_EMPTY; // slot THIS hop's merge mins into (last read two hops ago)
@@ -318,12 +343,23 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     uint32_t j = j0 + r * NW;
                     if (j < n_new) { ids[r] = s.s_new[j]; nrows = r + 1; }
                 }
+                uint32_t abyte = 0, abit = 0;
+                if (filt_level && lane < R && j0 + lane * NW < n_new) { // lane r fetches row r's allow bit alongside the rows
+                    const uint32_t e = s.s_new[j0 + lane * NW];
+                    abyte = allow[e >> 3];
+                    abit = e & 7u;
+                }
                 if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd);
                 else wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
+                const unsigned long long amask = FILT ? __ballot((abyte >> abit) & 1u) : 0ull;
                 if (lane == 0) {
 #pragma unroll
                     for (int r = 0; r < R; r++)
-                        if (r < nrows) s.s_key[j0 + r * NW] = make_key(dd[r], ids[r]);
+                        if (r < nrows) {
+                            const uint64_t key = make_key(dd[r], ids[r]);
+                            s.s_key[j0 + r * NW] = key;
+                            if (filt_level) s_keyR[j0 + r * NW] = ((amask >> r) & 1ull) ? key : ~0ull;
+                        }
                 }
             }
 #ifdef LEANN_STAMPS
@@ -374,6 +410,40 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 cand = min(cand, (uint32_t)__shfl_xor((int)cand, 32, 64));
                 if (lane == 0 && cand != LEANN_EMPTY) atomicMin(next_slot, cand);
             }
+            if (filt_level) {
+                // R <- kf best of R ∪ {allowed new keys}: the same merge by rank, on the blanked copy of the new keys.
+                // Skipped (uniformly) when no allowed new key beats the current kf-th.
+                uint64_t *Rc = R0 + rcur * kfp, *Rn = R0 + (rcur ^ 1) * kfp;
+                const uint64_t thr = rsize == kf ? Rc[kf - 1] : ~0ull;
+                uint32_t n_in = 0;
+                for (uint32_t j = 0; j < n_new; j += 64) n_in += __popcll(__ballot(j + lane < n_new && s_keyR[j + lane] < thr));
+                if (n_in) {
+                    const ulonglong2 *kr = reinterpret_cast<const ulonglong2 *>(s_keyR);
+                    for (uint32_t it = tid; it < rsize + n_new; it += NW * 64) {
+                        const bool isR = it < rsize;
+                        const uint64_t k = isR ? Rc[it] : s_keyR[it - rsize];
+                        if (k >= thr && !isR) continue; // disallowed, or cannot enter a full list
+                        uint32_t cnt = 0;
+#pragma unroll 4
+                        for (uint32_t j = 0; j < n_pad; j += 2) {
+                            const ulonglong2 v = kr[j >> 1];
+                            cnt += (v.x < k) + (v.y < k);
+                        }
+                        uint32_t rank = isR ? it + cnt : cnt;
+                        if (!isR) {
+                            uint32_t lo = 0, hi = rsize;
+                            while (lo < hi) {
+                                uint32_t mid = (lo + hi) >> 1;
+                                if (Rc[mid] < k) lo = mid + 1; else hi = mid;
+                            }
+                            rank += lo;
+                        }
+                        if (rank < kf) Rn[rank] = k;
+                    }
+                    rsize = min(rsize + n_in, kf);
+                    rcur ^= 1;
+                }
+            }
 #ifdef LEANN_STAMPS
             const uint64_t stD = __builtin_amdgcn_s_memtime();
 #endif
@@ -415,8 +485,8 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         }
         return;
     }
-    const uint32_t nout = min(wsize, a.k);
-    uint64_t *Wc = W0 + cur * efp;
+    const uint32_t nout = FILT ? rsize : min(wsize, a.k);
+    uint64_t *Wc = FILT ? R0 + rcur * kfp : W0 + cur * efp;
     for (uint32_t t = tid; t < a.k; t += NW * 64) {
         size_t o = (size_t)qi * a.k + t;
         if (t < nout) {
@@ -455,6 +525,21 @@ __global__ void __launch_bounds__(NW * 64) beam_search_kernel(GraphView g, Searc
     uint32_t qi = blockIdx.x;
     if (qi >= a.nq) return;
     beam_search_one<T, R, NW, false>(g, a, qi, smem);
+}
+// filtered search (allow-bitmap): answers come from the R list
+template <int T, int R, int NW>
+__global__ void __launch_bounds__(NW * 64) beam_search_filtered_kernel(GraphView g, SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    beam_search_one<T, R, NW, false, true>(g, a, qi, smem);
+}
+template <int T, int R, int NW>
+__global__ void __launch_bounds__(NW * 64) beam_search_feat_filtered_kernel(GraphView g, SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    beam_search_one<T, R, NW, true, true>(g, a, qi, smem);
 }
 // recompute-on instantiation: rows are bf16 features + inline norm, queries are W q
 template <int T, int R, int NW>

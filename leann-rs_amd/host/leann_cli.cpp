@@ -24,6 +24,7 @@ struct SearchArgs {
     std::string format = "text";
     std::optional<std::string> query_prompt_template, embedding_mode, query_vector_file;
     std::string device = "0";
+    bool device_filter = false;
 };
 
 static void usage_search() {
@@ -45,6 +46,7 @@ static void usage_search() {
          "      --embedding-mode <MODE>        (additive) override the index's embedding mode; `synthetic` works offline\n"
          "      --query-vector-file <FILE>     (additive) raw f32 query embedding instead of embedding the query text\n"
          "      --device <N>                   (additive) HIP device ordinal [default: 0]\n"
+         "      --device-filter                (additive) evaluate --filter inside the GPU traversal instead of 5x over-fetch + post-filter\n"
          "  -h, --help                         Print help");
 }
 
@@ -71,6 +73,7 @@ static int run_search(int argc, char **argv) {
         else if (name == "--top-k") a.top_k = std::stoul(val());
         else if (name == "--complexity") a.complexity = std::stoul(val());
         else if (name == "--show-metadata") a.show_metadata = true;
+        else if (name == "--device-filter") a.device_filter = true;
         else if (name == "-f" || name == "--filter") a.filter = val();
         else if (name == "--hybrid") a.hybrid = true;
         else if (name == "--auto-hybrid") a.auto_hybrid = parse_bool(val());
@@ -149,6 +152,7 @@ static int run_search(int argc, char **argv) {
         auto q = embed_query(a.query);
         SearchOptions opts(a.top_k, a.complexity);
         if (filter) opts.with_filter(*filter);
+        if (filter && a.device_filter) opts.with_device_filter(*a.filter);
         if (use_hybrid) opts.with_hybrid(a.query, a.hybrid_alpha);
         results = searcher.search_with_options(q, opts);
     }

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -439,7 +440,13 @@ struct SearchOptions {
     bool hybrid = false;
     float hybrid_alpha = 0.7f; // searcher.rs:47
     std::optional<std::string> query_text;
+    // Additive: evaluate the metadata filter INSIDE the graph traversal (allow-bitmap over
+    // positions, leann_backend_search_filtered) instead of over-fetching 5*top_k and post-filtering (:129-133,
+    // :190-194).  `filter_key` names the filter for the bitmap cache (the CLI passes the filter text).
+    bool device_filter = false;
+    std::string filter_key;
     SearchOptions(size_t k, size_t c) : top_k(k), complexity(c) {}
+    SearchOptions &with_device_filter(std::string key) { device_filter = true; filter_key = std::move(key); return *this; }
     SearchOptions &with_filter(MetadataFilter f) { filter = std::move(f); return *this; }
     SearchOptions &with_hybrid(std::string q, float alpha) { hybrid = true; hybrid_alpha = alpha; query_text = std::move(q); return *this; }
 };
@@ -486,7 +493,15 @@ class IndexSearcher {
         if (query_embedding.size() != leann_backend_dims(backend_.get()))
             throw Error("query embedding has " + std::to_string(query_embedding.size()) + " dimensions, index has " +
                         std::to_string(leann_backend_dims(backend_.get())));
-        check(leann_backend_search(backend_.get(), query_embedding.data(), fetch_k, opts.complexity, keys.data(), dists.data(), &n));
+        if (opts.filter && opts.device_filter) {
+            // every returned position already passes the filter, so no over-fetch is needed for it
+            if (!opts.hybrid) { fetch_k = opts.top_k; }
+            const std::vector<uint8_t> &bm = allow_bitmap(*opts.filter, opts.filter_key);
+            check(leann_backend_search_filtered(backend_.get(), query_embedding.data(), fetch_k, opts.complexity, bm.data(),
+                                                keys.data(), dists.data(), &n));
+        } else {
+            check(leann_backend_search(backend_.get(), query_embedding.data(), fetch_k, opts.complexity, keys.data(), dists.data(), &n));
+        }
         std::vector<std::pair<size_t, float>> vector_results;
         for (size_t i = 0; i < n; i++) vector_results.emplace_back((size_t)keys[i], dists[i]); // score = backend distance (N1)
         if (opts.hybrid && opts.query_text) { // :146-169
@@ -542,9 +557,28 @@ class IndexSearcher {
         if (!bm25_) bm25_ = std::make_shared<Bm25Scorer>(Bm25Scorer::build(get_all_texts()));
         return *bm25_;
     }
+    // one pass over the passage metadata per distinct filter (the index is immutable while open); bit i = position i
+    const std::vector<uint8_t> &allow_bitmap(const MetadataFilter &f, const std::string &key) const {
+        std::lock_guard<std::mutex> lk(*bm25_mu_);
+        if (!key.empty()) {
+            auto it = bitmaps_->find(key);
+            if (it != bitmaps_->end()) return it->second;
+        }
+        const size_t n = leann_backend_len(backend_.get());
+        std::vector<uint8_t> bm((n + 7) / 8, 0);
+        for (size_t i = 0; i < n; i++) {
+            std::string id = i < id_map_.size() ? id_map_[i] : std::to_string(i);
+            try {
+                if (f.matches(passages_.get(id).metadata)) bm[i >> 3] |= (uint8_t)(1u << (i & 7));
+            } catch (...) {} // unreadable passage: never returned (the post-filter path skips it with a warning too)
+        }
+        if (bitmaps_->size() >= 16) bitmaps_->clear();
+        return (*bitmaps_)[key.empty() ? std::string("\x01anon") : key] = std::move(bm);
+    }
     PassageStore passages_;
     std::shared_ptr<leann_backend> backend_;
     std::vector<std::string> id_map_;
+    std::shared_ptr<std::map<std::string, std::vector<uint8_t>>> bitmaps_ = std::make_shared<std::map<std::string, std::vector<uint8_t>>>();
     mutable std::shared_ptr<Bm25Scorer> bm25_;
     std::shared_ptr<std::mutex> bm25_mu_ = std::make_shared<std::mutex>();
 };

@@ -384,6 +384,11 @@ typedef struct {
     uint64_t *exp;
     uint32_t nexp, capexp; /* expanded nodes of the last layer (Vamana build) */
     uint64_t stats[3];
+    /* filtered search: every allowed key evaluated on the final layer (its seed included) */
+    const uint8_t *allow;
+    int collect;
+    uint64_t *F;
+    uint32_t nF, capF;
 } ctx_t;
 
 static ctx_t *ctx_new(uint64_t n, uint32_t ef) {
@@ -402,7 +407,17 @@ static void ctx_free(ctx_t *c) {
     free(c->C);
     free(c->W);
     free(c->exp);
+    free(c->F);
     free(c);
+}
+static void filt_push(ctx_t *c, uint64_t k) {
+    uint32_t id = key_id(k);
+    if (!((c->allow[id >> 3] >> (id & 7)) & 1)) return;
+    if (c->nF == c->capF) {
+        c->capF = c->capF ? c->capF * 2 : 1024;
+        c->F = (uint64_t *)realloc(c->F, (size_t)c->capF * 8);
+    }
+    c->F[c->nF++] = k;
 }
 static void ctx_new_epoch(ctx_t *c, uint64_t n) {
     if (++c->epoch == 0) {
@@ -485,6 +500,7 @@ static void search_layer_heap(const orc_graph *g, const float *q, const uint64_t
     }
     for (uint32_t i = 0; i < nep; i++) {
         c->stamp[key_id(ep[i])] = c->epoch;
+        if (c->collect) filt_push(c, ep[i]);
         minheap_push(c, ep[i]);
         maxheap_push(c, ep[i]);
         if (c->nW > ef) maxheap_pop(c);
@@ -504,6 +520,7 @@ static void search_layer_heap(const orc_graph *g, const float *q, const uint64_t
             c->stamp[e] = c->epoch;
             uint64_t k = mk_key(gdist(g, q, e), e);
             c->stats[0]++;
+            if (c->collect) filt_push(c, k);
             if (c->nW < ef || k < c->W[0]) {
                 minheap_push(c, k);
                 maxheap_push(c, k);
@@ -528,6 +545,7 @@ static void search_layer_list(const orc_graph *g, const float *q, const uint64_t
     uint8_t *done = (uint8_t *)calloc(L + 2, 1);
     for (uint32_t i = 0; i < nep; i++) {
         c->stamp[key_id(ep[i])] = c->epoch;
+        if (c->collect) filt_push(c, ep[i]);
         uint32_t p = c->nW;
         while (p && c->W[p - 1] > ep[i]) { c->W[p] = c->W[p - 1]; p--; }
         c->W[p] = ep[i];
@@ -551,6 +569,7 @@ static void search_layer_list(const orc_graph *g, const float *q, const uint64_t
             c->stamp[e] = c->epoch;
             uint64_t k = mk_key(gdist(g, q, e), e);
             c->stats[0]++;
+            if (c->collect) filt_push(c, k);
             if (c->nW == L && k > c->W[L - 1]) continue;
             uint32_t pos = c->nW < L ? c->nW : L - 1; /* slot that falls off / new tail */
             while (pos && c->W[pos - 1] > k) {
@@ -585,11 +604,24 @@ static void graph_search_ctx(const orc_graph *g, const float *q, uint32_t k, uin
         search_layer(g, q, &best, 1, 1, lv, algo, c);
         best = c->W[0];
     }
+    c->collect = c->allow != NULL;
+    c->nF = 0;
     search_layer(g, q, &best, 1, ef, 0, algo, c);
-    uint32_t m = c->nW < k ? c->nW : k;
+    c->collect = 0;
+    /* Filtered search (replaces the over-fetch + post-filter of searcher.rs:129-133,:190-194):
+     * the traversal is the unfiltered one; the answer is the k best ALLOWED keys among everything whose distance
+     * the final layer evaluated (its seed included) - a superset of the beam, at no extra traversal cost. */
+    const uint64_t *src = c->W;
+    uint32_t ns = c->nW;
+    if (c->allow) {
+        qsort(c->F, c->nF, 8, cmp_u64);
+        src = c->F;
+        ns = c->nF;
+    }
+    uint32_t m = ns < k ? ns : k;
     for (uint32_t i = 0; i < m; i++) {
-        keys[i] = key_id(c->W[i]);
-        dists[i] = key_dist(c->W[i]);
+        keys[i] = key_id(src[i]);
+        dists[i] = key_dist(src[i]);
     }
     *n_out = m;
 }
@@ -597,6 +629,16 @@ static void graph_search_ctx(const orc_graph *g, const float *q, uint32_t k, uin
 int orc_graph_search(const orc_graph *g, const float *q, uint32_t k, uint32_t ef, int algo,
                      uint64_t *keys, float *dists, uint32_t *n_out, uint64_t *stats) {
     ctx_t *c = ctx_new(g->n, ef > k ? ef : k);
+    graph_search_ctx(g, q, k, ef, algo, c, keys, dists, n_out);
+    if (stats) memcpy(stats, c->stats, sizeof(c->stats));
+    ctx_free(c);
+    return 0;
+}
+
+int orc_graph_search_filtered(const orc_graph *g, const float *q, uint32_t k, uint32_t ef, int algo,
+                              const uint8_t *allow, uint64_t *keys, float *dists, uint32_t *n_out, uint64_t *stats) {
+    ctx_t *c = ctx_new(g->n, ef > k ? ef : k);
+    c->allow = allow;
     graph_search_ctx(g, q, k, ef, algo, c, keys, dists, n_out);
     if (stats) memcpy(stats, c->stats, sizeof(c->stats));
     ctx_free(c);
@@ -613,12 +655,15 @@ typedef struct {
     float *dists;
     uint32_t *counts;
     uint64_t *stats;
+    const uint8_t *allow; /* optional: bitmap(s) of allowed positions, allow_stride bytes apart per query (0 = shared) */
+    uint64_t allow_stride;
 } batch_job;
 static void *batch_worker(void *p) {
     batch_job *j = (batch_job *)p;
     ctx_t *c = ctx_new(j->g->n, j->ef > j->k ? j->ef : j->k);
     for (uint64_t i = j->lo; i < j->hi; i++) {
         c->stats[0] = c->stats[1] = c->stats[2] = 0;
+        c->allow = j->allow ? j->allow + i * j->allow_stride : NULL;
         graph_search_ctx(j->g, j->Q + i * j->g->d, j->k, j->ef, j->algo, c, j->keys + i * j->k,
                          j->dists + i * j->k, j->counts + i);
         if (j->stats) memcpy(j->stats + i * 3, c->stats, sizeof(c->stats));
@@ -626,15 +671,23 @@ static void *batch_worker(void *p) {
     ctx_free(c);
     return NULL;
 }
+int orc_graph_search_filtered_batch(const orc_graph *g, const float *Q, uint64_t nq, uint32_t k, uint32_t ef,
+                                    int algo, uint32_t nthreads, const uint8_t *allow, uint64_t allow_stride,
+                                    uint64_t *keys, float *dists, uint32_t *counts, uint64_t *stats);
 int orc_graph_search_batch(const orc_graph *g, const float *Q, uint64_t nq, uint32_t k, uint32_t ef,
                            int algo, uint32_t nthreads, uint64_t *keys, float *dists,
                            uint32_t *counts, uint64_t *stats) {
+    return orc_graph_search_filtered_batch(g, Q, nq, k, ef, algo, nthreads, NULL, 0, keys, dists, counts, stats);
+}
+int orc_graph_search_filtered_batch(const orc_graph *g, const float *Q, uint64_t nq, uint32_t k, uint32_t ef,
+                                    int algo, uint32_t nthreads, const uint8_t *allow, uint64_t allow_stride,
+                                    uint64_t *keys, float *dists, uint32_t *counts, uint64_t *stats) {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > nq) nthreads = nq ? (uint32_t)nq : 1;
     pthread_t *th = (pthread_t *)malloc(nthreads * sizeof(pthread_t));
     batch_job *jobs = (batch_job *)malloc(nthreads * sizeof(batch_job));
     for (uint32_t t = 0; t < nthreads; t++) {
-        batch_job j = {g, Q, nq, nq * t / nthreads, nq * (t + 1) / nthreads, k, ef, algo, keys, dists, counts, stats};
+        batch_job j = {g, Q, nq, nq * t / nthreads, nq * (t + 1) / nthreads, k, ef, algo, keys, dists, counts, stats, allow, allow_stride};
         jobs[t] = j;
         if (nthreads == 1) batch_worker(&jobs[t]);
         else pthread_create(&th[t], NULL, batch_worker, &jobs[t]);

@@ -94,6 +94,13 @@ int orc_graph_search(const orc_graph *g, const float *q, uint32_t k, uint32_t ef
 int orc_graph_search_batch(const orc_graph *g, const float *Q, uint64_t nq, uint32_t k, uint32_t ef,
                            int algo, uint32_t nthreads, uint64_t *keys, float *dists,
                            uint32_t *counts, uint64_t *stats /* [nq*3] or NULL */);
+/* Filtered variants: `allow` = bitmap over positions (bit i of byte i>>3); same traversal as the
+ * unfiltered search, answer = k best allowed keys among all keys evaluated on the final layer. */
+int orc_graph_search_filtered(const orc_graph *g, const float *q, uint32_t k, uint32_t ef, int algo,
+                              const uint8_t *allow, uint64_t *keys, float *dists, uint32_t *n_out, uint64_t *stats);
+int orc_graph_search_filtered_batch(const orc_graph *g, const float *Q, uint64_t nq, uint32_t k, uint32_t ef,
+                                    int algo, uint32_t nthreads, const uint8_t *allow, uint64_t allow_stride,
+                                    uint64_t *keys, float *dists, uint32_t *counts, uint64_t *stats);
 
 /* ---- top-k merge of per-shard results (new) --------------------------------- */
 void orc_merge_topk(const uint64_t *keys, const float *dists, const uint32_t *counts,

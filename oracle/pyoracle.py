@@ -65,6 +65,8 @@ def lib():
                                        f32p, u32p, u64p]
         L.orc_graph_search_batch.argtypes = [C.c_void_p, f32p, C.c_uint64, C.c_uint32, C.c_uint32,
                                              C.c_int, C.c_uint32, u64p, f32p, u32p, u64p]
+        L.orc_graph_search_filtered_batch.argtypes = [C.c_void_p, f32p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                      C.c_int, C.c_uint32, u8p, C.c_uint64, u64p, f32p, u32p, u64p]
         L.orc_merge_topk.argtypes = [u64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u64p,
                                      f32p, u32p]
         L.orc_hybrid_rerank.argtypes = [u64p, f32p, C.c_uint32, f32p, C.c_uint64, C.c_float, u64p,
@@ -183,6 +185,20 @@ class Graph:
         stats = np.zeros((nq, 3), np.uint64)
         lib().orc_graph_search_batch(self.h, _p(Q, f32p), nq, k, ef, algo, nthreads, _p(keys, u64p),
                                      _p(dists, f32p), _p(counts, u32p), _p(stats, u64p))
+        return keys, dists, counts, stats
+
+    def search_filtered_batch(self, Q, k, ef, allow, algo=0, nthreads=1):
+        """allow: uint8 bitmap [ceil(n/8)] shared by all queries, or [nq, stride] one per query."""
+        Q = np.ascontiguousarray(Q, np.float32)
+        allow = np.ascontiguousarray(allow, np.uint8)
+        nq = Q.shape[0]
+        stride = 0 if allow.ndim == 1 else allow.shape[1]
+        keys = np.full((nq, k), 0xFFFFFFFFFFFFFFFF, np.uint64)
+        dists = np.full((nq, k), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        stats = np.zeros((nq, 3), np.uint64)
+        lib().orc_graph_search_filtered_batch(self.h, _p(Q, f32p), nq, k, ef, algo, nthreads, _p(allow, u8p), stride,
+                                              _p(keys, u64p), _p(dists, f32p), _p(counts, u32p), _p(stats, u64p))
         return keys, dists, counts, stats
 
     def __del__(self):

@@ -155,6 +155,46 @@ def test_hnsw_two_formulations_agree_and_recall(po):
     assert keys[0] == 123 and abs(dists[0]) < 1e-6
 
 
+def test_filtered_search_restatement(po):
+    """Filtered search: same walk, answer = best allowed keys among everything evaluated on level 0.
+    Properties: both formulations agree; all-ones bitmap == unfiltered; only allowed ids, ascending; at least as good as
+    post-filtering the beam; no reference behaviour to pin (searcher.rs post-filters) -> parity unpinned."""
+    n, d, k, ef = 4000, 128, 10, 48
+    rng = np.random.default_rng(5)
+    X = synth(po, n, d)
+    Q = synth(po, 50, d, stream=1)
+    G = po.Graph.build_hnsw(X, M=16, efc=64)
+    ones = np.full((n + 7) // 8, 0xFF, np.uint8)
+    uk, ud, uc, ust = G.search_batch(Q, k, ef, 0)
+    fk, fd, fc, fst = G.search_filtered_batch(Q, k, ef, ones, 0)
+    assert (fk == uk).all() and (fd == ud).all() and (fc == uc).all() and (fst == ust).all()
+    allowed = rng.random(n) < 0.1
+    bm = np.packbits(allowed, bitorder="little")
+    k0, d0, c0, s0 = G.search_filtered_batch(Q, k, ef, bm, 0)
+    k1, d1, c1, s1 = G.search_filtered_batch(Q, k, ef, bm, 1, nthreads=4)
+    assert (k0 == k1).all() and (d0 == d1).all() and (c0 == c1).all() and (s0 == s1).all()
+    assert (s0 == ust).all()                                   # the walk itself is the unfiltered one
+    bk, bd, bc, _ = G.search_batch(Q, ef, ef, 0)               # the whole beam
+    truth = np.argsort(-(Q @ X[allowed].T), axis=1, kind="stable")[:, :k]
+    truth = np.nonzero(allowed)[0][truth]
+    hits = 0
+    for i in range(len(Q)):
+        ids = k0[i, : c0[i]].astype(np.int64)
+        assert allowed[ids].all() and (np.diff(d0[i, : c0[i]]) >= 0).all()
+        beam_ok = [j for j in range(bc[i]) if allowed[int(bk[i, j])]][:k]
+        assert c0[i] >= len(beam_ok)
+        for t, j in enumerate(beam_ok):                        # never worse than post-filtering the beam
+            assert d0[i, t] <= bd[i, j]
+        hits += len(set(ids.tolist()) & set(truth[i].tolist()))
+    assert hits / (len(Q) * k) > 0.6
+    # one bitmap per query
+    per = np.packbits(rng.random((len(Q), n)) < 0.2, axis=1, bitorder="little")
+    pk, pd, pc, _ = G.search_filtered_batch(Q, k, ef, per, 0)
+    for i in (0, 17, 49):
+        sk, sd, sc, _ = G.search_filtered_batch(Q[i : i + 1], k, ef, per[i], 0)
+        assert (sk[0] == pk[i]).all() and sc[0] == pc[i]
+
+
 def test_config0_plumbing_10k_x_128(po):
     """BASELINE configs[0]: 10k x 128 random f32 vectors, HNSW ef=64 (CPU, plumbing)."""
     X = synth(po, 10000, 128, r=0)

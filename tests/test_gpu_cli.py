@@ -101,3 +101,22 @@ def test_pruned_index_uses_recompute_search(index_dir):
     # and score == 1 - distance within 1e-5
     d = [x["score"] for x in json.loads(r2.stdout)]
     assert np.allclose(np.array(sc), 1.0 - np.array(d), atol=1e-5)
+
+
+def test_device_filter_flag(index_dir):
+    """--device-filter: the metadata filter becomes an allow-bitmap evaluated inside the traversal.
+    A 2 %-selective filter starves the reference's 5x over-fetch + post-filter; the in-traversal filter still fills top-k."""
+    q = "vector database embedding search and some more words"
+    flt = "lines<12"
+    post = _run("search", q, "-i", str(index_dir / "idx"), "--top-k", "6", "--format", "json", "-f", flt)
+    dev = _run("search", q, "-i", str(index_dir / "idx"), "--top-k", "6", "--format", "json", "-f", flt, "--device-filter")
+    assert post.returncode == 0 and dev.returncode == 0, dev.stderr
+    rp, rd = json.loads(post.stdout), json.loads(dev.stdout)
+    assert all(x["metadata"]["lines"] < 12 for x in rp + rd)
+    assert len(rd) == 6 and len(rp) <= len(rd)
+    sd = [x["score"] for x in rd]
+    assert sd == sorted(sd)
+    for a, b in zip(rp, rd):  # never worse than post-filtering
+        assert b["score"] <= a["score"] + 1e-7
+    # the two docs of the query's own topic among the 12 allowed ones come first
+    assert {x["id"] for x in rd[:2]} == {"3", "9"}

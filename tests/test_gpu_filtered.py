@@ -1,0 +1,143 @@
+"""-m gpu: filtered traversal (allow-bitmap inside the kernel) vs the oracle, bit-exact.
+The reference has no such path (it over-fetches 5*top_k and post-filters, searcher.rs:129-133,:190-194), so the pinned
+behaviour is the restatement in oracle/oracle.c:graph_search_ctx — "parity unpinned" against the reference itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import SEED, recall_at_k, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bitmap(rng, n, sel, nq=None):
+    shape = (n,) if nq is None else (nq, n)
+    allowed = rng.random(shape) < sel
+    return np.packbits(allowed, axis=-1, bitorder="little"), allowed
+
+
+def _same(G, s, Q, k, ef, bm, algo=0):
+    ok, od, oc, ost = G.search_filtered_batch(Q, k, ef, bm, algo, nthreads=8)
+    s.stats(reset=True)
+    gk, gd, gc = s.search_filtered_batch(Q, k, ef, bm)
+    st = s.stats()
+    assert (gc == oc).all()
+    assert (gk == ok).all(), f"ids differ in {(gk != ok).any(axis=1).sum()} of {len(Q)} queries"
+    assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+    assert st["n_dist_evals"] == int(ost[:, 0].sum()) and st["n_hops_base"] == int(ost[:, 1].sum())
+    return gk, gd, gc
+
+
+@pytest.mark.parametrize("n,d,M,ef,nq", [(4000, 128, 16, 64, 64), (3000, 768, 32, 100, 600), (1500, 1536, 8, 32, 40)])
+def test_filtered_hnsw_matches_oracle(la, po, gpu, n, d, M, ef, nq):
+    rng = np.random.default_rng(n)
+    X = synth(po, n, d)
+    Q = synth(po, nq, d, stream=1)
+    G = po.Graph.build_hnsw(X, M=M, efc=64)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, M, 2 * M, G.max_level, G.entry, lv, uo, a0, aU)
+    for sel in (0.5, 0.1, 0.01):
+        bm, allowed = _bitmap(rng, n, sel)
+        for k, e in ((10, ef), (1, 1), (ef, ef), (7, 3)):
+            gk, gd, gc = _same(G, s, Q, k, e, bm)
+            for i in range(len(Q)):
+                ids = gk[i, : gc[i]].astype(np.int64)
+                assert allowed[ids].all()          # nothing disallowed comes back
+                assert (np.diff(gd[i, : gc[i]]) >= 0).all()
+    # one bitmap per query
+    bmq, allowed_q = _bitmap(rng, n, 0.2, nq=len(Q))
+    gk, gd, gc = _same(G, s, Q, 10, ef, bmq)
+    for i in range(len(Q)):
+        assert allowed_q[i, gk[i, : gc[i]].astype(np.int64)].all()
+    # all-ones == unfiltered; all-zeros == empty
+    ones = np.full((n + 7) // 8, 0xFF, np.uint8)
+    uk, ud, uc = s.search_batch(Q, 10, ef)
+    gk, gd, gc = s.search_filtered_batch(Q, 10, ef, ones)
+    assert (gk == uk).all() and (gd.view(np.uint32) == ud.view(np.uint32)).all() and (gc == uc).all()
+    gk, gd, gc = s.search_filtered_batch(Q, 10, ef, np.zeros((n + 7) // 8, np.uint8))
+    assert (gc == 0).all() and (gk == np.iinfo(np.uint64).max).all()
+    # single-query entry point
+    bm, allowed = _bitmap(rng, n, 0.3)
+    k1, d1 = s.search_filtered(Q[5], 10, ef, bm)
+    ok, od, oc, _ = G.search_filtered_batch(Q[5:6], 10, ef, bm)
+    assert (k1 == ok[0, : oc[0]]).all() and (d1.view(np.uint32) == od[0, : oc[0]].view(np.uint32)).all()
+    with pytest.raises(la.LeannError):
+        s.search_filtered(Q[5], 10, ef, bm[:-2])
+    s.close()
+
+
+def test_filtered_vamana_and_hbm_table(la, po, gpu, monkeypatch):
+    n, d, R = 5000, 128, 24
+    rng = np.random.default_rng(7)
+    X = synth(po, n, d, r=0)
+    Q = synth(po, 100, d, stream=1, r=0)
+    G = po.Graph.build_vamana(X, R=R, L=48, alpha=1.2)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.DiskAnn, X, R, R, 0, G.entry, lv, uo, a0, aU)
+    bm, _ = _bitmap(rng, n, 0.1)
+    _same(G, s, Q, 10, 64, bm, algo=1)
+    monkeypatch.setenv("LEANN_DEBUG_HASH_BITS", "8")  # every query migrates to the HBM visited table mid-search
+    _same(G, s, Q, 10, 32, bm, algo=1)
+    assert s.stats()["n_table_overflow"] == len(Q)
+    s.close()
+
+
+def test_in_traversal_filter_beats_post_filter(la, po, gpu):
+    """Quality: at 5 % selectivity the in-kernel filter (pool = every evaluated node) finds far more of the true filtered
+    top-10 than the reference's 5x over-fetch + post-filter, for the same traversal."""
+    n, d, M, ef, k = 30000, 128, 16, 64, 10
+    rng = np.random.default_rng(11)
+    X = synth(po, n, d)
+    Q = synth(po, 200, d, stream=1)
+    dX = la.DeviceArray.from_host(X)
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, d, M, 100)
+    bm, allowed = _bitmap(rng, n, 0.05)
+    idx = np.nonzero(allowed)[0]
+    sc = Q @ X[idx].T
+    truth = idx[np.argsort(-sc, axis=1, kind="stable")[:, :k]]
+    fk, _, fc = s.search_filtered_batch(Q, k, ef, bm)
+    pk, _, pc = s.search_batch(Q, 5 * k, ef)  # searcher.rs:129-133
+    post = np.full((len(Q), k), -1, np.int64)
+    for i in range(len(Q)):
+        keep = [int(x) for x in pk[i, : pc[i]] if allowed[int(x)]][:k]
+        post[i, : len(keep)] = keep
+    r_in = recall_at_k(np.where(np.arange(k)[None, :] < fc[:, None], fk.astype(np.int64), -1), truth)
+    r_post = recall_at_k(post, truth)
+    assert r_in > r_post + 0.2, (r_in, r_post)
+    assert r_in > 0.7, r_in
+    s.close()
+
+
+def test_filtered_recompute_on_graph(la, po, gpu):
+    """feature-row (no stored vectors) instantiation of the filtered kernel vs the oracle over the same bytes"""
+    n, h, d, M, k = 6000, 256, 768, 16, 10
+    rng = np.random.default_rng(3)
+    Lc, chk = la.lib(), la._native.check
+    F = po.synth_features(SEED, h, 64, 1.0, 0, 0, n)
+    W = po.synth_weights(SEED, h, d)
+    Q = po.recompute_encode(po.synth_features(SEED, h, 64, 1.0, 1, 0, 64), W)
+    dF, dW = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W)
+    r = C.c_void_p()
+    chk(Lc.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))
+    hb = C.c_void_p()
+    chk(Lc.leann_recompute_build_index(r, 0, M, 64, C.byref(hb)))
+    s = la.BackendSearcher(hb, la.BackendType.Hnsw)
+    fh, rb = C.c_uint32(0), C.c_uint32(0)
+    chk(Lc.leann_backend_feature_rows_export(hb, C.byref(fh), C.byref(rb), None))
+    rows = np.zeros((n, rb.value), np.uint8)
+    chk(Lc.leann_backend_feature_rows_export(hb, None, None, rows.ctypes.data))
+    g = s.graph_export()
+    Gr = po.Graph.from_arrays(np.zeros((n, 1), np.float32), M, 2 * M, g["max_level"], g["entry"], g["levels"], g["upper_off"],
+                              g["adj0"], g["adjU"])
+    Gr.set_features(rows, fh.value, rb.value)
+    PQ = po.project_queries(W, Q, fh.value)
+    for sel in (0.3, 0.02):
+        bm, allowed = _bitmap(rng, n, sel)
+        ok, od, oc, ost = Gr.search_filtered_batch(PQ, k, 64, bm, 0, 8)
+        gk, gd, gc = s.search_filtered_batch(Q, k, 64, bm)
+        assert (gc == oc).all() and (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+        for i in range(len(Q)):
+            assert allowed[gk[i, : gc[i]].astype(np.int64)].all()
+    s.close()
+    Lc.leann_recompute_close(r)
