@@ -104,6 +104,26 @@ __device__ __forceinline__ float4 vec_load4_guard(const float *__restrict__ v, u
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Block-wide bitonic sort of n (power of two, <= SEG) u64 keys in LDS, ascending (scan.hip / recompute.hip top-k).
+// ---------------------------------------------------------------------------------------------
+#define SEG 2048
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *k, int n /* power of two */) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
+                int lo = 2 * i - (i & (stride - 1));
+                int hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                uint64_t a = k[lo], b = k[hi];
+                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 #define HIP_CHECK_RET(expr)                                                                  \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \

@@ -17,7 +17,6 @@
 #include "../../include/leann_backend.h"
 #include <algorithm>
 
-#define SEG 2048
 
 // ------------------------------------------------------------------------------------------------
 // score_mfma_kernel: S[q][i] for a tile of 128 rows x 64 queries on the f32 matrix cores.
@@ -94,24 +93,6 @@ __global__ void __launch_bounds__(256) score_mfma_kernel(const float *__restrict
             if (q1 < nq) S[(size_t)q1 * n_rows + row] = acc1[reg];
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Block-wide bitonic sort of SEG u64 keys in LDS (ascending), 256 threads.
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t *k, int n /* power of two */) {
-    for (int size = 2; size <= n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
-                int lo = 2 * i - (i & (stride - 1));
-                int hi = lo + stride;
-                bool up = ((lo & size) == 0);
-                uint64_t a = k[lo], b = k[hi];
-                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
-            }
-        }
-    }
-    __syncthreads();
 }
 
 // scores S[q][n_rows] -> cand[q][seg][k]; key = ~orderable(score) << 32 | (row0 + row)   (position < 2^32)

@@ -9,4 +9,4 @@ for f in api build gen scan recompute; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_out/stamps/libleann_hip_stamps.so gpurun_out/stamps/*.o
-LEANN_LIB=$PWD/gpurun_out/stamps/libleann_hip_stamps.so python scripts/stamps.py "$@"
+if [ "$1" = "fstat" ]; then shift; LEANN_LIB=$PWD/gpurun_out/stamps/libleann_hip_stamps.so python scripts/stamps_fstat.py "$@"; else LEANN_LIB=$PWD/gpurun_out/stamps/libleann_hip_stamps.so python scripts/stamps.py "$@"; fi

@@ -174,3 +174,86 @@ def test_recompute_on_graph_search(la, po, gpu):
     s2.close()
     s.close()
     Lc.leann_recompute_close(r)
+
+
+def _search(la, r, dQ, nq, k, dM=None):
+    L, chk = la.lib(), la._native.check
+    dk, ds, dc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    chk(L.leann_recompute_search_batch_device(r, dQ.ptr, nq, k, dM.ptr if dM is not None else None, dk.ptr, ds.ptr, dc.ptr, None))
+    la.sync()
+    return dk.to_host(), ds.to_host(), dc.to_host()
+
+
+def test_multi_chunk_candidate_emission(la, po, gpu, monkeypatch):
+    """> 128k passages: chunks after the first emit their few survivors straight from the fused kernel (no score slab).
+    Must equal the slab path bit for bit (same kernel arithmetic), agree with the general kernel within 1e-5, and honour
+    the allow mask; spot-checked against the oracle restatement on the winners."""
+    n, h, d, nq, k = 700000, 256, 768, 70, 10
+    L, chk = la.lib(), la._native.check
+    dF, dW = la.DeviceArray((n, h), np.uint16), la.DeviceArray((h, d), np.uint16)
+    chk(L.leann_synth_features_device(SEED, h, 64, 4096, 1.0, 0, 0, n, dF.ptr, None))
+    chk(L.leann_synth_weights_device(SEED, h, d, dW.ptr, None))
+    W = po.synth_weights(SEED, h, d)
+    Q = po.recompute_encode(po.synth_features(SEED, h, 4096, 1.0, 1, 0, nq, r_int=64), W)
+    dQ = la.DeviceArray.from_host(Q)
+    r = C.c_void_p()
+    chk(L.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 5000, C.byref(r)))
+    gk, gs, gc = _search(la, r, dQ, nq, k)
+    assert (gc == k).all() and (np.diff(gs, axis=1) <= 0).all()
+    monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")           # same fused kernel, score slab + segment top-k
+    sk, ss, sc = _search(la, r, dQ, nq, k)
+    assert (gk == sk).all() and (gs.view(np.uint32) == ss.view(np.uint32)).all()
+    monkeypatch.setenv("LEANN_DEBUG_FUSED_V1", "1")          # general kernel (different accumulation order)
+    vk, vs, vc = _search(la, r, dQ, nq, k)
+    assert np.abs(vs - gs).max() <= 1e-5 and (vk == gk).mean() > 0.98
+    monkeypatch.delenv("LEANN_DEBUG_NO_EMIT")
+    monkeypatch.delenv("LEANN_DEBUG_FUSED_V1")
+    # a handle without the fragment-major feature copy (row-major loads): the same arithmetic, bit for bit
+    monkeypatch.setenv("LEANN_RECOMPUTE_NO_TILED", "1")
+    r2 = C.c_void_p()
+    chk(L.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 5000, C.byref(r2)))
+    rk, rs, rc = _search(la, r2, dQ, nq, k)
+    assert (rk == gk).all() and (rs.view(np.uint32) == gs.view(np.uint32)).all()
+    L.leann_recompute_close(r2)
+    monkeypatch.delenv("LEANN_RECOMPUTE_NO_TILED")
+    # oracle on the winners: score = <l2norm(W^T f), q>  (recompute.rs:96-103)
+    F = dF.to_host()
+    for i in (0, 33, 69):
+        pos = (gk[i] - 5000).astype(np.int64)
+        E = po.recompute_encode(F[pos], W)
+        assert np.abs(E @ Q[i] - gs[i]).max() <= 1e-5
+    # allow mask (every 5th position) through the emission path
+    mask = np.zeros((n + 7) // 8, np.uint8)
+    idx = np.arange(0, n, 5)
+    np.bitwise_or.at(mask, idx >> 3, (1 << (idx & 7)).astype(np.uint8))
+    dM = la.DeviceArray.from_host(mask)
+    mk, ms, mc = _search(la, r, dQ, nq, k, dM)
+    assert ((mk - 5000) % 5 == 0).all() and (mc == k).all()
+    monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")
+    nk, ns, nc = _search(la, r, dQ, nq, k, dM)
+    assert (mk == nk).all() and (ms.view(np.uint32) == ns.view(np.uint32)).all()
+    L.leann_recompute_close(r)
+
+
+def test_candidate_list_overflow_falls_back(la, po, gpu, monkeypatch):
+    """Adversarial order: the score rises with the position, so every row of the later chunks beats the running k-th best and
+    the per-query candidate lists overflow; the search must notice and repeat on the slab path (same answer)."""
+    n, h, d, nq, k = 300000, 256, 768, 3, 10
+    L, chk = la.lib(), la._native.check
+    rng = np.random.default_rng(1)
+    W = po.synth_weights(SEED, h, d)
+    u, v = rng.standard_normal(h).astype(np.float32), rng.standard_normal(h).astype(np.float32)
+    t = (np.arange(n, dtype=np.float32) / n)[:, None]
+    Ff = (1 - t) * u[None, :] + t * v[None, :]
+    F = ((Ff.view(np.uint32) + 0x8000) >> 16).astype(np.uint16)            # bf16 (round half up is fine here)
+    qf = ((v.view(np.uint32) + 0x8000) >> 16).astype(np.uint16)[None, :]
+    Q = np.repeat(po.recompute_encode(qf, W), nq, axis=0)                  # queries = embedding of v: closest to the LAST rows
+    dF, dW, dQ = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W), la.DeviceArray.from_host(Q)
+    r = C.c_void_p()
+    chk(L.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))
+    gk, gs, gc = _search(la, r, dQ, nq, k)
+    monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")
+    sk, ss, sc = _search(la, r, dQ, nq, k)
+    assert (gk == sk).all() and (gs.view(np.uint32) == ss.view(np.uint32)).all()
+    assert gk.min() > n - 2000                                             # the winners are at the far end
+    L.leann_recompute_close(r)
