@@ -519,6 +519,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sbuf = smem;                                     // [2][SUBB]
     float *sNrm = reinterpret_cast<float *>(smem + 2 * SUBB);       // [NWV][RB * 32] sums of squares of a wave's passages
+    float *sThr = sNrm + NWV * RB * 32;                             // [64] emission thresholds of the query tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform in an SGPR: DMA addresses stay scalar + lane offset
     const int l31 = lane & 31, lh = lane >> 5;
@@ -572,6 +573,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     };
 
     if (blockIdx.x >= n_units) return;
+    if (em.thr && tid < 64) sThr[tid] = em.thr[tid]; // visible to every wave long before its first use (a barrier per sub-slice)
     // Every workgroup does the same work per unit, so all 256 would fetch their next features in the same few microseconds
     // and queue on HBM (~14 000 cycles per unit).  On long launches the workgroups of an XCD start 1/8 of a unit apart.
     if (n_units >= 8ull * gridDim.x) {
@@ -673,12 +675,14 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                                            ssq[1][14], p1[14], ssq[0][15], p0[15], ssq[1][15], p1[15]);
                     }
                 });
+                // the last MFMAs' results: hipcc does not see the MFMA -> VALU hazard (no hardware interlock); the operands pin every
+                // compiler-generated reader or copy of the accumulators (loop-carried across visits) below the pad
+                asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accA[0]), "+v"(accA[1]), "+v"(accB[0]), "+v"(accB[1]));
 #ifdef LEANN_STAMPS
                 const uint64_t tN = __builtin_amdgcn_s_memtime();
                 stCW += tN - tB;
 #endif
                 if (j == nsw - 1) { // all columns seen: flush the last tile, then row norms (candle.rs:218-225)
-                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); // the last MFMAs' results (hipcc does not see the hazard)
 #pragma unroll
                     for (int rb = 0; rb < RB; rb++)
 #pragma unroll
@@ -712,13 +716,15 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 const uint64_t nprow0 = (last_unit ? unit : next_unit) * UNIT + (uint64_t)wave * (RB * 32);
 #endif
                 f32x16 sc[RB];
-                bf16x8 gq[RING + 1];
-                static_for<RING>([&gq, &waddr](auto fc) __attribute__((always_inline)) {
-                    constexpr int f = decltype(fc)::value;
-                    FSTAT_DS_READ(gq[f], waddr, (f / 3) * KSB + (f % 3) * 1024);
-                });
-                auto g_loop = [&sc, &gq, &a, &waddr, &nprow0, &load_features](auto pfc) __attribute__((always_inline)) {
+                // (the ring's first reads sit inside each instantiation: with a branch between an asm read and the statement that
+                // waits for it, hipcc copies the not-yet-landed destination registers at the join)
+                auto g_loop = [&sc, &a, &waddr, &nprow0, &load_features](auto pfc) __attribute__((always_inline)) {
                     constexpr bool PF = decltype(pfc)::value;
+                    bf16x8 gq[RING + 1];
+                    static_for<RING>([&gq, &waddr](auto fc) __attribute__((always_inline)) {
+                        constexpr int f = decltype(fc)::value;
+                        FSTAT_DS_READ(gq[f], waddr, (f / 3) * KSB + (f % 3) * 1024);
+                    });
                     static_for<3 * KS>([&sc, &gq, &a, &waddr, &nprow0, &load_features](auto fc) __attribute__((always_inline)) {
                         // k-step major (pieces hi, lo, lo2 innermost): a feature fragment is dead after its k-step, so the next
                         // unit's feature loads spread over the whole visit instead of bunching in the last third
@@ -737,26 +743,39 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 };
                 if (qt == 1) g_loop(std::true_type{});
                 else g_loop(std::false_type{});
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1])); // as above: no reader of the score tiles above the pad
 #ifdef LEANN_STAMPS
                 if (qt == 0) stGL += __builtin_amdgcn_s_memtime() - tB; else stGL1 += __builtin_amdgcn_s_memtime() - tB;
 #endif
                 if (em.thr) {
+                    // thresholds of this lane's 16 queries from the LDS copy (4 x ds_read_b128); one pass that only ORs compare
+                    // masks, and a branch into the (rare) emission code per passage block instead of one per score
                     float th[16];
 #pragma unroll
-                    for (int reg = 0; reg < 16; reg++) th[reg] = em.thr[qt * 32 + 4 * lh + (reg & 3) + 8 * (reg >> 2)];
+                    for (int g4 = 0; g4 < 4; g4++) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(sThr + qt * 32 + 4 * lh + 8 * g4);
+                        th[4 * g4] = t4.x; th[4 * g4 + 1] = t4.y; th[4 * g4 + 2] = t4.z; th[4 * g4 + 3] = t4.w;
+                    }
 #pragma unroll
                     for (int rb = 0; rb < RB; rb++) {
                         const uint64_t row = prow0 + rb * 32 + l31;
+                        float sv[16];
+                        bool any = false;
 #pragma unroll
                         for (int reg = 0; reg < 16; reg++) {
-                            const float sv = sc[rb][reg] * inv[rb];
-                            if (sv >= th[reg] && row < n) { // rare: a few rows per query and chunk
-                                const uint64_t pos = em.pos0 + row;
-                                if (!em.allow || ((em.allow[pos >> 3] >> (pos & 7)) & 1)) {
-                                    const uint32_t q = qt * 32 + 4 * lh + (reg & 3) + 8 * (reg >> 2);
-                                    const uint32_t slot = atomicAdd(&em.cnt[q], 1u);
-                                    if (slot < em.cap) em.list[(size_t)q * em.cap + slot] = ((uint64_t)(~f32_orderable(sv)) << 32) | (uint32_t)pos;
+                            sv[reg] = sc[rb][reg] * inv[rb];
+                            any |= sv[reg] >= th[reg];
+                        }
+                        if (any && row < n) {
+                            const uint64_t pos = em.pos0 + row;
+                            if (!em.allow || ((em.allow[pos >> 3] >> (pos & 7)) & 1)) {
+#pragma unroll
+                                for (int reg = 0; reg < 16; reg++) {
+                                    if (sv[reg] >= th[reg]) {
+                                        const uint32_t q = qt * 32 + 4 * lh + (reg & 3) + 8 * (reg >> 2);
+                                        const uint32_t slot = atomicAdd(&em.cnt[q], 1u);
+                                        if (slot < em.cap) em.list[(size_t)q * em.cap + slot] = ((uint64_t)(~f32_orderable(sv[reg])) << 32) | (uint32_t)pos;
+                                    }
                                 }
                             }
                         }
@@ -886,7 +905,7 @@ static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows,
     const bool fused = Gp != nullptr;
     if (fused && use_fstat(r)) {
         // features stationary in registers (the common shape: h = 256, dims = 384 / 768)
-        const size_t lds2 = 2 * 16 * 128 * 32 + 4 * 128 * 4; // two 64-KiB sub-slice buffers + per-wave norm exchange
+        const size_t lds2 = 2 * 16 * 128 * 32 + 4 * 128 * 4 + 64 * 4; // two 64-KiB sub-slice buffers + per-wave norm exchange + thresholds
         const uint64_t unit_rows = 4 * LEANN_FSTAT_RB * 32, units = (rows + unit_rows - 1) / unit_rows; // NWV * RB * 32 passages per unit
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device);

@@ -1,0 +1,62 @@
+"""Static guard for fused_fstat_kernel's hand-counted LDS reads (recompute.hip): hipcc does not know that the destination of
+an inline-asm ds_read is still in flight until the asm s_waitcnt that retires it, so it may copy / read that register early
+(seen once: a phi copy at a branch between the ring's first reads and the loop).  Compiles the file to ISA and fails if any
+compiler-generated vector instruction reads such a register.  Usage: python scripts/check_fstat_asm.py  (exit code 1 = violation)"""
+import os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def vregs(tok):
+    out = set()
+    for m in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def scan(asm_text):
+    bad, kernels = [], 0
+    for m in re.finditer(r'^(_Z\d+fused_fstat_kernel\w*):', asm_text, re.M):
+        kernels += 1
+        body = asm_text[m.end():asm_text.index('s_endpgm', m.end())].split('\n')
+        pending, inasm = [], False
+        for ln, l in enumerate(body):
+            t = l.strip()
+            if 'ASMSTART' in t:
+                inasm = True
+                continue
+            if 'ASMEND' in t:
+                inasm = False
+                continue
+            if not t or t[0] in ';.' or t.endswith(':'):
+                continue
+            if inasm:
+                if t.startswith('ds_read_b128'):
+                    pending.append(vregs(t.split(',')[0]))
+                elif t.startswith('s_waitcnt') and 'lgkmcnt' in t:
+                    n = int(re.search(r'lgkmcnt\((\d+)\)', t).group(1))
+                    pending = pending[-n:] if n > 0 else []
+            elif t.startswith('v_') and ',' in t:
+                srcs = vregs(','.join(t.split(None, 1)[1].split(',')[1:]))
+                if any(srcs & p for p in pending):
+                    bad.append((m.group(1), ln, t))
+    return kernels, bad
+
+
+def main():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "recompute.s")
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", os.path.join(ROOT, "leann-rs_amd/csrc/recompute.hip"), "-o", out]
+        subprocess.run(cmd, check=True, capture_output=True)
+        kernels, bad = scan(open(out).read())
+    print(f"{kernels} fused_fstat_kernel instantiations scanned, {len(bad)} early reads of in-flight asm ds_read destinations")
+    for b in bad[:10]:
+        print("  ", b)
+    return 1 if bad or kernels == 0 else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -73,3 +73,13 @@ def test_diskann_add_is_refused(la, tmp_path):
     with pytest.raises(la.LeannError) as e:  # mod.rs:93-98
         la.BackendBuilder(la.BackendType.DiskAnn).add_to_index(np.zeros((1, 8), np.float32), str(tmp_path / "d.leann"), 8, 0)
     assert e.value.code == 5 and "does not support incremental updates" in str(e.value)
+
+
+def test_fused_kernel_asm_reads_are_not_consumed_early():
+    """fused_fstat_kernel counts its LDS fragment reads by hand (inline asm); hipcc must not touch their destination
+    registers before the asm wait that retires them.  scripts/check_fstat_asm.py compiles recompute.hip to ISA and scans."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_fstat_asm.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "2 fused_fstat_kernel instantiations scanned, 0 early reads" in r.stdout
