@@ -153,6 +153,36 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
            "roofline": roof}
     if shard:
         out["end_to_end_qps"] = B * steps / elapsed
+    # ---- CPU baseline: the oracle's literal recompute.rs:86-109 (embed every passage, dot, sort) on a bounded sample -------
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import pyoracle as po
+            from concurrent.futures import ThreadPoolExecutor
+            cores = host_cores()
+            ns = min(rows, 10_000_000)  # the reference re-embeds ALL passages for every query: one whole query is timed (~10 s)
+            Fh = F[:ns].cpu().numpy().view(np.uint16)
+            Wh = W.cpu().numpy().view(np.uint16)
+            qh = Q[0, :d].contiguous().cpu().numpy()
+            bounds = [(ns * t // cores, ns * (t + 1) // cores) for t in range(cores)]
+
+            def part(b):  # ctypes releases the GIL: one slice per host thread
+                E = po.recompute_encode(Fh[b[0]:b[1]], Wh)
+                return po.scan_topk(E, qh, k, mode=0)
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(part, bounds[:cores]))  # touch
+                t0 = time.perf_counter()
+                list(ex.map(part, bounds))
+                cpu_s = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": 1.0 / (cpu_s * rows / ns), "unit": "queries/s", "cores": cores, "kind": "port",
+                "sample": f"one query over {ns} of the {rows} passages (oracle/oracle.c: orc_recompute_encode + orc_scan_topk, the literal "
+                          f"embed-everything-then-dot order of recompute.rs:86-109), {cores} host threads, {cpu_s:.2f} s; value = extrapolated "
+                          f"to all {rows} passages per query",
+            }
+            log(f"cpu baseline: {ns} passages of one query in {cpu_s:.2f} s on {cores} threads -> {out['cpu_baseline']['value']:.4f} q/s at {rows} passages")
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
