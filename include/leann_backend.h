@@ -184,6 +184,12 @@ int leann_recompute_create_pooled(const uint16_t *d_features, const uint8_t *d_m
 int leann_recompute_search_batch_device(const leann_recompute *r, const float *d_queries, size_t nq,
                                         size_t top_k, const uint8_t *d_allow_mask, uint64_t *d_keys,
                                         float *d_scores, uint32_t *d_counts, void *stream);
+/* host-memory twins (SURVEY.md §8b "Recompute boundary"): plain host pointers in, results out; the handle made by
+ * create_host owns a device copy of the features.  keys/scores are [nq x top_k] (unused tail: UINT64_MAX / -inf). */
+int leann_recompute_create_host(const uint16_t *features, size_t n, size_t h, const uint16_t *weights,
+                                size_t dims, int device, uint64_t key_offset, leann_recompute **out);
+int leann_recompute_search_batch(const leann_recompute *r, const float *queries, size_t nq, size_t top_k,
+                                 const uint8_t *allow_mask, uint64_t *keys, float *scores, uint32_t *counts);
 /* materialise embeddings of rows [row0, row0+rows) into d_out [rows x ceil4(dims)] (validation) */
 int leann_recompute_encode_device(const leann_recompute *r, uint64_t row0, uint64_t rows, float *d_out,
                                   void *stream);

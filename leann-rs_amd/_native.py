@@ -66,6 +66,9 @@ SIGNATURES = {
     "leann_recompute_create": (C.c_int, [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(vp)]),
     "leann_recompute_create_pooled": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_uint64,
                                                C.POINTER(vp)]),
+    "leann_recompute_create_host": (C.c_int, [C.POINTER(C.c_uint16), C.c_size_t, C.c_size_t, C.POINTER(C.c_uint16), C.c_size_t, C.c_int,
+                                             C.c_uint64, C.POINTER(vp)]),
+    "leann_recompute_search_batch": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, u8p, u64p, f32p, u32p]),
     "leann_recompute_search_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp]),
     "leann_recompute_encode_device": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
     "leann_recompute_len": (C.c_size_t, [vp]),

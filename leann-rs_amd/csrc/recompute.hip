@@ -485,9 +485,7 @@ struct FstatEmit {
     const uint8_t *allow;  // optional early filter over positions (recompute.rs:66-71)
     uint64_t pos0;         // position of the chunk's first row
 };
-#ifndef LEANN_FSTAT_RB
-#define LEANN_FSTAT_RB 2 // scripts/variant.sh "-DLEANN_FSTAT_RB=2" for the A/B
-#endif
+#define LEANN_FSTAT_RB 2 // 32-passage blocks per wave (the per-k-step asm statements are written for two)
 // Fragment-major copy of the features for fused_fstat_kernel: Ft[block of 32 rows][k-step][lane = lh * 32 + row][8 bf16], i.e.
 // the 1 KiB a wave loads per (block, k-step) is contiguous (8 full lines per instruction instead of 32 quarter lines of a
 // row-major read: the row-major form costs ~170 issue cycles per load next to the MFMAs).  Rows are padded to whole units.
@@ -535,9 +533,6 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     // every M0 write waits for the previous LDS-DMA to have consumed it (~175 cycles per DMA when each one has its own).
     auto stage = [&](int j, int buf) {
         unsigned char *dst = sbuf + buf * SUBB;
-#if defined(LEANN_FSTAT_ABL) && LEANN_FSTAT_ABL == 1 // timing-only ablation (scripts/variant.sh): no weight DMA, results are wrong
-        if (j >= 0) return;
-#endif
 #pragma unroll
         for (int t = 0; t < KS / NWV; t++) {
             const int ks = wave + NWV * t;
@@ -710,11 +705,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 const int qt = j - nsw;
                 // last sub-slice of the unit (qt == 1): each feature register is refilled for the next unit right after its last
                 // use; unconditional (the last unit re-reads its own rows) so that no branch or register copy sits between MFMAs
-#if defined(LEANN_FSTAT_ABL) && LEANN_FSTAT_ABL == 6 // timing-only ablation: prefetch always from the first rows (cache resident)
-                const uint64_t nprow0 = (uint64_t)wave * (RB * 32);
-#else
                 const uint64_t nprow0 = (last_unit ? unit : next_unit) * UNIT + (uint64_t)wave * (RB * 32);
-#endif
                 f32x16 sc[RB];
                 // (the ring's first reads sit inside each instantiation: with a branch between an asm read and the statement that
                 // waits for it, hipcc copies the not-yet-landed destination registers at the join)
@@ -878,6 +869,7 @@ struct leann_recompute {
     uint64_t *sCandA = nullptr, *sCandB = nullptr, *sBest = nullptr;
     size_t capS = 0, capGp = 0, capCand = 0, capBest = 0;
     uint4 *Ft = nullptr;            // fragment-major copy of F (tile_features_kernel), made by the first exhaustive search
+    uint16_t *ownF = nullptr;       // leann_recompute_create_host: the handle's own copy of the features
     unsigned char *sEmit = nullptr; // [64 f32 thr | 64 u32 cnt | u32 overflow | pad | 64 x EMIT_CAP u64 list]
     size_t capEmit = 0;
 };
@@ -1015,6 +1007,65 @@ extern "C" int leann_recompute_create_pooled(const uint16_t *d_features, const u
     (*out)->mask = d_mask;
     return LEANN_OK;
 }
+// Host-memory twins of create / search (SURVEY.md §8b "Recompute boundary": plain host pointers in, results out).
+extern "C" int leann_recompute_create_host(const uint16_t *features, size_t n, size_t h, const uint16_t *weights, size_t dims,
+                                           int device, uint64_t key_offset, leann_recompute **out) {
+    if (!out || (n && !features) || !weights || h == 0 || dims == 0) {
+        leann_set_error("leann_recompute_create_host: null/zero argument");
+        return LEANN_ERR_INVALID;
+    }
+    int ndev = 0;
+    leann_device_count(&ndev);
+    if (device < 0 || device >= ndev) {
+        leann_set_error("HIP device %d not available (%d visible). This library has no CPU fallback.", device, ndev);
+        return LEANN_ERR_DEVICE;
+    }
+    HIP_CHECK_RET(hipSetDevice(device));
+    uint16_t *dF = nullptr, *dW = nullptr;
+    HIP_CHECK_RET(hipMalloc((void **)&dF, std::max<size_t>(n * h, 8) * 2));
+    if (hipMalloc((void **)&dW, h * dims * 2) != hipSuccess) { (void)hipFree(dF); leann_set_error("hipMalloc failed"); return LEANN_ERR_DEVICE; }
+    int rc = LEANN_OK;
+    if ((n && hipMemcpy(dF, features, n * h * 2, hipMemcpyHostToDevice) != hipSuccess) ||
+        hipMemcpy(dW, weights, h * dims * 2, hipMemcpyHostToDevice) != hipSuccess) {
+        leann_set_error("H2D copy of the encoder inputs failed");
+        rc = LEANN_ERR_DEVICE;
+    }
+    if (rc == LEANN_OK) rc = leann_recompute_create(dF, n, h, dW, dims, device, key_offset, out);
+    (void)hipFree(dW); // copied and re-tiled by create
+    if (rc != LEANN_OK) { (void)hipFree(dF); return rc; }
+    (*out)->ownF = dF;
+    return LEANN_OK;
+}
+extern "C" int leann_recompute_search_batch(const leann_recompute *r, const float *queries, size_t nq, size_t top_k,
+                                            const uint8_t *allow_mask, uint64_t *keys, float *scores, uint32_t *counts) {
+    if (!r || !queries || !keys || !scores || !counts || top_k == 0) {
+        leann_set_error("leann_recompute_search_batch: null/zero argument");
+        return LEANN_ERR_INVALID;
+    }
+    if (nq == 0) return LEANN_OK;
+    HIP_CHECK_RET(hipSetDevice(r->device));
+    const size_t nmask = allow_mask ? (r->n + 7) / 8 : 0;
+    unsigned char *buf = nullptr; // [queries | keys | scores | counts | mask]
+    const size_t oq = 0, ok = oq + nq * r->d * 4, os = ok + nq * top_k * 8, oc = os + nq * top_k * 4, om = (oc + nq * 4 + 15) & ~(size_t)15;
+    HIP_CHECK_RET(hipMalloc((void **)&buf, om + nmask + 16));
+    int rc = LEANN_OK;
+    if (hipMemcpy(buf + oq, queries, nq * r->d * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        (nmask && hipMemcpy(buf + om, allow_mask, nmask, hipMemcpyHostToDevice) != hipSuccess)) {
+        leann_set_error("H2D copy of the queries failed");
+        rc = LEANN_ERR_DEVICE;
+    }
+    if (rc == LEANN_OK)
+        rc = leann_recompute_search_batch_device(r, (const float *)(buf + oq), nq, top_k, nmask ? buf + om : nullptr, (uint64_t *)(buf + ok),
+                                                 (float *)(buf + os), (uint32_t *)(buf + oc), nullptr);
+    if (rc == LEANN_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(keys, buf + ok, nq * top_k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(scores, buf + os, nq * top_k * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(counts, buf + oc, nq * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+        leann_set_error("recompute search: device error: %s", hipGetErrorString(hipGetLastError()));
+        rc = LEANN_ERR_DEVICE;
+    }
+    (void)hipFree(buf);
+    return rc;
+}
 extern "C" void leann_recompute_close(leann_recompute *r) {
     if (!r) return;
     (void)hipFree(r->Wp);
@@ -1026,6 +1077,7 @@ extern "C" void leann_recompute_close(leann_recompute *r) {
     (void)hipFree(r->sBest);
     (void)hipFree(r->sEmit);
     (void)hipFree(r->Ft);
+    (void)hipFree(r->ownF);
     delete r;
 }
 extern "C" size_t leann_recompute_len(const leann_recompute *r) { return r ? r->n : 0; }

@@ -257,3 +257,25 @@ def test_candidate_list_overflow_falls_back(la, po, gpu, monkeypatch):
     assert (gk == sk).all() and (gs.view(np.uint32) == ss.view(np.uint32)).all()
     assert gk.min() > n - 2000                                             # the winners are at the far end
     L.leann_recompute_close(r)
+
+
+def test_host_pointer_twins(la, po, gpu):
+    """leann_recompute_create_host / leann_recompute_search_batch (SURVEY 8b recompute boundary: host pointers) == device API"""
+    n, h, d, nq, k = 5000, 256, 768, 9, 7
+    L, chk, F, W, Q, r, keep = _mk(la, po, n, h, d, nq)
+    dQ = la.DeviceArray.from_host(Q)
+    gk, gs, gc = _search(la, r, dQ, nq, k)
+    u16p, f32p, u64p, u32p, u8p = (C.POINTER(t) for t in (C.c_uint16, C.c_float, C.c_uint64, C.c_uint32, C.c_uint8))
+    rh = C.c_void_p()
+    chk(L.leann_recompute_create_host(F.ctypes.data_as(u16p), n, h, W.ctypes.data_as(u16p), d, 0, 0, C.byref(rh)))
+    hk, hs, hc = np.zeros((nq, k), np.uint64), np.zeros((nq, k), np.float32), np.zeros(nq, np.uint32)
+    chk(L.leann_recompute_search_batch(rh, Q.ctypes.data_as(f32p), nq, k, None, hk.ctypes.data_as(u64p), hs.ctypes.data_as(f32p),
+                                       hc.ctypes.data_as(u32p)))
+    assert (hk == gk).all() and (hs.view(np.uint32) == gs.view(np.uint32)).all() and (hc == gc).all()
+    mask = np.zeros((n + 7) // 8, np.uint8)
+    mask[::2] = 0x55
+    chk(L.leann_recompute_search_batch(rh, Q.ctypes.data_as(f32p), nq, k, mask.ctypes.data_as(u8p), hk.ctypes.data_as(u64p),
+                                       hs.ctypes.data_as(f32p), hc.ctypes.data_as(u32p)))
+    assert (((hk >> 3) % 2 == 0) & (hk % 2 == 0)).all()
+    L.leann_recompute_close(rh)
+    L.leann_recompute_close(r)
