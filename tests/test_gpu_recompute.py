@@ -46,7 +46,8 @@ def test_encode_matches_oracle(la, po, gpu, n, h, d):
     L.leann_recompute_close(r)
 
 
-@pytest.mark.parametrize("n,h,d,nq,k", [(6000, 256, 768, 70, 10), (2500, 64, 128, 5, 3), (4100, 128, 256, 64, 16)])
+@pytest.mark.parametrize("n,h,d,nq,k", [(6000, 256, 768, 70, 10), (2500, 64, 128, 5, 3), (4100, 128, 256, 64, 16),
+                                        (4500, 256, 384, 33, 5), (5000, 256, 512, 64, 12), (4200, 256, 600, 3, 10), (300, 256, 768, 2, 10)])
 def test_recompute_search_matches_restatement(la, po, gpu, n, h, d, nq, k):
     L, chk, F, W, Q, r, keep = _mk(la, po, n, h, d, nq)
     dQ = la.DeviceArray.from_host(Q)
