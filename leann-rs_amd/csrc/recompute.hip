@@ -464,7 +464,39 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
                    [q4] "+v"(Q4_), [q5] "+v"(Q5_)                                                                              \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [cnt] "i"(CNT_), [p0] "v"(P0_), [p1] "v"(P1_), [p2] "v"(P2_), [p3] "v"(P3_),        \
                    [p4] "v"(P4_), [p5] "v"(P5_) : "memory")
+// ... D variants carry one 1-KiB LDS-DMA piece of the NEXT sub-slice between the two MFMAs (M0 = LDS destination, written in the
+// same statement; source = scalar base + per-lane offset + immediate, the immediate also offsets the LDS side).  Spread one
+// piece per four k-steps the DMA issue hides in the MFMA gap (+0.5 cycles per MFMA); issued back to back at the top of a visit
+// the 64 pieces of a sub-slice cost ~1 000 cycles (the CU's 64 B/clk vector-memory path).
+#define FSTAT_DMA "s_mov_b32 m0, %[ld]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:%[doff]\n\t"
+#define FSTAT_W_RD_D(C0_, C1_, A0_, A1_, B_, NB_, ADDR_, OFF_, CNT_, VO_, SB_, LD_, DOFF_)                                    \
+    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_DMA FSTAT_MM "%[x1], %[f1], %[bb], %[x1]"    \
+                 : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [nb] "=&v"(NB_)                                              \
+                 : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_), [vo] "v"(VO_), [sb] "s"(SB_), \
+                   [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
+#define FSTAT_W_RD_SQ1_D(C0_, C1_, A0_, A1_, B_, NB_, ADDR_, OFF_, CNT_, Q0_, P0_, Q1_, P1_, VO_, SB_, LD_, DOFF_)            \
+    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_DMA                        \
+                 FSTAT_MM "%[x1], %[f1], %[bb], %[x1]\n\t" FSTAT_SQ(q1, p1)                                                  \
+                 : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [nb] "=&v"(NB_), [q0] "+v"(Q0_), [q1] "+v"(Q1_)               \
+                 : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_), [p0] "v"(P0_), [p1] "v"(P1_), \
+                   [vo] "v"(VO_), [sb] "s"(SB_), [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
+#define FSTAT_W_NR_SQ1_D(C0_, C1_, A0_, A1_, B_, CNT_, Q0_, P0_, Q1_, P1_, VO_, SB_, LD_, DOFF_)                              \
+    asm volatile(FSTAT_W_HEAD_NR FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_DMA                        \
+                 FSTAT_MM "%[x1], %[f1], %[bb], %[x1]\n\t" FSTAT_SQ(q1, p1)                                                  \
+                 : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [q0] "+v"(Q0_), [q1] "+v"(Q1_)                                \
+                 : [f0] "a"(A0_), [f1] "a"(A1_), [cnt] "i"(CNT_), [p0] "v"(P0_), [p1] "v"(P1_), [vo] "v"(VO_), [sb] "s"(SB_),  \
+                   [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
 // G: acc += A(query-projection frag, VGPR) x B(feature frag, AGPR)
+#define FSTAT_G_RD_D(C0_, C1_, A0_, A1_, G_, NG_, ADDR_, OFF_, CNT_, VO_, SB_, LD_, DOFF_)                                  \
+    asm volatile("s_waitcnt lgkmcnt(%[cnt])\n\tds_read_b128 %[ng], %[addr] offset:%[off]\n\t" FSTAT_MM "%[x0], %[gg], %[f0], %[x0]\n\t" \
+                 FSTAT_DMA FSTAT_MM "%[x1], %[gg], %[f1], %[x1]"                                                             \
+                 : [x0] "+v"(C0_), [x1] "+v"(C1_), [gg] "+v"(G_), [ng] "=&v"(NG_)                                              \
+                 : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_), [vo] "v"(VO_), [sb] "s"(SB_), \
+                   [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
+#define FSTAT_G_NR_D(C0_, C1_, A0_, A1_, G_, CNT_, VO_, SB_, LD_, DOFF_)                                                    \
+    asm volatile("s_waitcnt lgkmcnt(%[cnt])\n\t" FSTAT_MM "%[x0], %[gg], %[f0], %[x0]\n\t" FSTAT_DMA FSTAT_MM "%[x1], %[gg], %[f1], %[x1]" \
+                 : [x0] "+v"(C0_), [x1] "+v"(C1_), [gg] "+v"(G_)                                                               \
+                 : [f0] "a"(A0_), [f1] "a"(A1_), [cnt] "i"(CNT_), [vo] "v"(VO_), [sb] "s"(SB_), [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
 #define FSTAT_G_RD(c0, c1, a0, a1, g, ng, addr, off, cnt)                                                                     \
     asm volatile("s_waitcnt lgkmcnt(%8)\n\tds_read_b128 %3, %6 offset:%7\n\t" FSTAT_MM "%0, %2, %4, %0\n\t" FSTAT_MM "%1, %2, %5, %1" \
                  : "+v"(c0), "+v"(c1), "+v"(g), "=&v"(ng) : "a"(a0), "a"(a1), "v"(addr), "i"(off), "i"(cnt) : "memory")
@@ -619,8 +651,20 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
 #ifdef LEANN_STAMPS
             const uint64_t tA = __builtin_amdgcn_s_memtime();
 #endif
-            if (j + 1 < nsub) stage(j + 1, buf ^ 1);
-            else if (!last_unit) stage(0, buf ^ 1);
+            // The next sub-slice (of this unit, or the first of the next one) is staged into the other buffer by LDS-DMA pieces
+            // carried inside this visit's MFMA stream: wave w owns k-steps w, w + 4, w + 8, w + 12, four 1-KiB pieces each (a G
+            // sub-slice has three; its fourth piece lands in the unused KiB of the k-step).  Staged on the last unit too
+            // (harmless; drained before the kernel ends).
+            const int jn = j + 1 < nsub ? j + 1 : 0;
+            const char *dsb[4];
+            uint32_t dld[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int ks = wave + NWV * t;
+                dsb[t] = jn < nsw ? reinterpret_cast<const char *>(Wp) + ((size_t)ks * dp + (size_t)jn * SUB) * 32
+                                  : reinterpret_cast<const char *>(Gp) + ((size_t)ks * 192 + (size_t)(jn - nsw) * 96) * 32;
+                dld[t] = lds_base + (uint32_t)(buf ^ 1) * SUBB + ks * KSB;
+            }
             if (j == 0) { // the unit's feature fragments have landed (vmcnt(0) above): pin them into their AGPRs here
 #pragma unroll
                 for (int rb = 0; rb < RB; rb++)
@@ -641,7 +685,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                     constexpr int f = decltype(fc)::value;
                     FSTAT_DS_READ(bq[f], waddr, (f % KS) * KSB + (f / KS) * 1024);
                 });
-                static_for<4 * KS>([&accA, &accB, &bq, &a, &ssq, &waddr](auto fc) __attribute__((always_inline)) {
+                static_for<4 * KS>([&accA, &accB, &bq, &a, &ssq, &waddr, &dsb, &dld, &goff](auto fc) __attribute__((always_inline)) {
                     constexpr int f = decltype(fc)::value, ct = f / KS, ks = f % KS, NF = 4 * KS;
                     f32x16 &c0 = (ct & 1) ? accB[0] : accA[0];
                     f32x16 &c1 = (ct & 1) ? accB[1] : accA[1];
@@ -655,12 +699,20 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                     f32x16 &p0 = (ct & 1) ? accA[0] : accB[0];
                     f32x16 &p1 = (ct & 1) ? accA[1] : accB[1];
                     constexpr int e = ks >= 2 ? ks - 2 : 0;
+                    constexpr bool dma = (f & 3) == 1;                    // piece f / 4 of the next sub-slice rides in this statement
+                    constexpr int dt = (f >> 2) >> 2, doff = ((f >> 2) & 3) * 1024; // its k-step group and immediate offset
                     if constexpr (ks < 2) {
                         if constexpr (ks == 0) FSTAT_W_RDZ(c0, c1, a[0][ks], a[1][ks], b, nb, waddr, noff, RING - 1);
+                        else if constexpr (dma) FSTAT_W_RD_D(c0, c1, a[0][ks], a[1][ks], b, nb, waddr, noff, RING - 1, goff, dsb[dt], dld[dt], doff);
                         else FSTAT_W_RD(c0, c1, a[0][ks], a[1][ks], b, nb, waddr, noff, RING - 1);
                     } else if constexpr (ks < KS - 1) {
-                        if constexpr (f + RING < NF) FSTAT_W_RD_SQ1(c0, c1, a[0][ks], a[1][ks], b, nb, waddr, noff, RING - 1, ssq[0][e], p0[e], ssq[1][e], p1[e]);
-                        else FSTAT_W_NR_SQ1(c0, c1, a[0][ks], a[1][ks], b, NF - f - 1, ssq[0][e], p0[e], ssq[1][e], p1[e]);
+                        if constexpr (f + RING < NF) {
+                            if constexpr (dma) FSTAT_W_RD_SQ1_D(c0, c1, a[0][ks], a[1][ks], b, nb, waddr, noff, RING - 1, ssq[0][e], p0[e], ssq[1][e], p1[e], goff, dsb[dt], dld[dt], doff);
+                            else FSTAT_W_RD_SQ1(c0, c1, a[0][ks], a[1][ks], b, nb, waddr, noff, RING - 1, ssq[0][e], p0[e], ssq[1][e], p1[e]);
+                        } else {
+                            if constexpr (dma) FSTAT_W_NR_SQ1_D(c0, c1, a[0][ks], a[1][ks], b, NF - f - 1, ssq[0][e], p0[e], ssq[1][e], p1[e], goff, dsb[dt], dld[dt], doff);
+                            else FSTAT_W_NR_SQ1(c0, c1, a[0][ks], a[1][ks], b, NF - f - 1, ssq[0][e], p0[e], ssq[1][e], p1[e]);
+                        }
                     } else {
                         if constexpr (f + RING < NF)
                             FSTAT_W_RD_SQ3(c0, c1, a[0][ks], a[1][ks], b, nb, waddr, noff, RING - 1, ssq[0][13], p0[13], ssq[1][13], p1[13],
@@ -709,25 +761,29 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 f32x16 sc[RB];
                 // (the ring's first reads sit inside each instantiation: with a branch between an asm read and the statement that
                 // waits for it, hipcc copies the not-yet-landed destination registers at the join)
-                auto g_loop = [&sc, &a, &waddr, &nprow0, &load_features](auto pfc) __attribute__((always_inline)) {
+                auto g_loop = [&sc, &a, &waddr, &nprow0, &load_features, &dsb, &dld, &goff](auto pfc) __attribute__((always_inline)) {
                     constexpr bool PF = decltype(pfc)::value;
                     bf16x8 gq[RING + 1];
                     static_for<RING>([&gq, &waddr](auto fc) __attribute__((always_inline)) {
                         constexpr int f = decltype(fc)::value;
                         FSTAT_DS_READ(gq[f], waddr, (f / 3) * KSB + (f % 3) * 1024);
                     });
-                    static_for<3 * KS>([&sc, &gq, &a, &waddr, &nprow0, &load_features](auto fc) __attribute__((always_inline)) {
+                    static_for<3 * KS>([&sc, &gq, &a, &waddr, &nprow0, &load_features, &dsb, &dld, &goff](auto fc) __attribute__((always_inline)) {
                         // k-step major (pieces hi, lo, lo2 innermost): a feature fragment is dead after its k-step, so the next
                         // unit's feature loads spread over the whole visit instead of bunching in the last third
                         constexpr int f = decltype(fc)::value, piece = f % 3, ks = f / 3, NF = 3 * KS;
                         bf16x8 &g = gq[f % (RING + 1)];
                         bf16x8 &ng = gq[(f + RING) % (RING + 1)];
                         constexpr int noff = ((f + RING) / 3) * KSB + ((f + RING) % 3) * 1024;
+                        constexpr bool dma = f % 3 == 1;                       // piece f / 3 of the next sub-slice
+                        constexpr int dt = (f / 3) >> 2, doff = ((f / 3) & 3) * 1024;
                         if constexpr (f + RING < NF) { // C[i = query][j = passage]
                             if constexpr (f == 0) FSTAT_G_RDZ(sc[0], sc[1], a[0][ks], a[1][ks], g, ng, waddr, noff, RING - 1);
+                            else if constexpr (dma) FSTAT_G_RD_D(sc[0], sc[1], a[0][ks], a[1][ks], g, ng, waddr, noff, RING - 1, goff, dsb[dt], dld[dt], doff);
                             else FSTAT_G_RD(sc[0], sc[1], a[0][ks], a[1][ks], g, ng, waddr, noff, RING - 1);
                         } else {
-                            FSTAT_G_NR(sc[0], sc[1], a[0][ks], a[1][ks], g, NF - f - 1);
+                            if constexpr (dma) FSTAT_G_NR_D(sc[0], sc[1], a[0][ks], a[1][ks], g, NF - f - 1, goff, dsb[dt], dld[dt], doff);
+                            else FSTAT_G_NR(sc[0], sc[1], a[0][ks], a[1][ks], g, NF - f - 1);
                         }
                         if constexpr (PF && piece == 2) load_features(a, nprow0, ks);
                     });
@@ -803,6 +859,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
 #endif
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pieces staged during the last visit: no DMA into LDS after the workgroup ends
 #ifdef LEANN_STAMPS
     if (tid == 0) {
         atomicAdd(&g_fstat_stamps[0], stW); atomicAdd(&g_fstat_stamps[1], stBar); atomicAdd(&g_fstat_stamps[2], stIss);
@@ -1163,7 +1220,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
         }
     }
     if (int e = grow_scratch((void **)&rw->sS, &rw->capS, sizeof(float) * 64 * chunk)) return e;
-    if (int e = grow_scratch((void **)&rw->sGp, &rw->capGp, r->hp * 192 * 2)) return e;
+    if (int e = grow_scratch((void **)&rw->sGp, &rw->capGp, r->hp * 192 * 2 + 1024)) return e; // + the fourth (unused) KiB piece of the last k-step
     {
         size_t capB = rw->capCand;
         if (int e = grow_scratch((void **)&rw->sCandA, &rw->capCand, sizeof(uint64_t) * nq * cand_len)) return e;
