@@ -656,13 +656,16 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
             // sub-slice has three; its fourth piece lands in the unused KiB of the k-step).  Staged on the last unit too
             // (harmless; drained before the kernel ends).
             const int jn = j + 1 < nsub ? j + 1 : 0;
+            const bool nw = jn < nsw;
+            const char *dbase = nw ? reinterpret_cast<const char *>(Wp) + (size_t)jn * (SUB * 32)
+                                   : reinterpret_cast<const char *>(Gp) + (size_t)(jn - nsw) * (96 * 32);
+            const uint32_t dstride = nw ? dp * 32 : 192 * 32; // bytes between k-steps of the source image
             const char *dsb[4];
             uint32_t dld[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int ks = wave + NWV * t;
-                dsb[t] = jn < nsw ? reinterpret_cast<const char *>(Wp) + ((size_t)ks * dp + (size_t)jn * SUB) * 32
-                                  : reinterpret_cast<const char *>(Gp) + ((size_t)ks * 192 + (size_t)(jn - nsw) * 96) * 32;
+                dsb[t] = dbase + (size_t)ks * dstride;
                 dld[t] = lds_base + (uint32_t)(buf ^ 1) * SUBB + ks * KSB;
             }
             if (j == 0) { // the unit's feature fragments have landed (vmcnt(0) above): pin them into their AGPRs here
@@ -1184,19 +1187,20 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     hipStream_t st = (hipStream_t)stream;
     const uint32_t k = (uint32_t)top_k;
     const size_t SEGSZ = 2048;
-    // geometric chunk schedule 128k, 512k, 2M, 4M, 4M ... : the first small chunks fix the running k-th best, after which
-    // topk_scores_kernel skips almost every segment unsorted
+    // slab path: geometric chunk schedule 128k, 512k, 2M, 4M, 4M ... : the first small chunks fix the running k-th best, after
+    // which topk_scores_kernel skips almost every segment unsorted
     std::vector<std::pair<size_t, size_t>> chunks; // (row0, rows)
     {
-        size_t pos = 0, len = (size_t)128 << 10;
+        // with candidate emission only the first chunk needs a score slab: 64k rows fix a first k-th-best bound, the next 448k
+        // tighten it (~k * 448k / 64k survivors per query), everything else goes through ONE persistent launch
+        const bool emit_schedule = emit_ok && use_fstat(r) && !getenv("LEANN_DEBUG_NO_EMIT");
+        size_t pos = 0, len = emit_schedule ? (size_t)64 << 10 : (size_t)128 << 10;
         while (pos < r->n) {
             size_t rows = std::min(len, r->n - pos);
             chunks.emplace_back(pos, rows);
             pos += rows;
-            len = std::min<size_t>(len * 4, (size_t)4 << 20);
-            // candidate emission needs no score slab: everything after the first two chunks (640k rows, enough for a tight
-            // k-th-best bound) goes through ONE persistent launch
-            if (emit_ok && use_fstat(r) && !getenv("LEANN_DEBUG_NO_EMIT") && chunks.size() >= 2) len = r->n;
+            if (emit_schedule) len = chunks.size() == 1 ? (size_t)448 << 10 : r->n;
+            else len = std::min<size_t>(len * 4, (size_t)4 << 20);
         }
     }
     const size_t n_chunks = chunks.size();
