@@ -83,3 +83,30 @@ def test_fused_kernel_asm_reads_are_not_consumed_early():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_fstat_asm.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "2 fused_fstat_kernel instantiations scanned, 0 early reads" in r.stdout
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu(la):
+    """filtered search / recompute host twins: argument errors come back as LEANN_ERR_INVALID (1) with a message, or as
+    LEANN_ERR_DEVICE (4, "no CPU fallback") when only the missing GPU stands in the way — never a crash, never CPU compute."""
+    import numpy as np
+    L = la.lib()
+    n_out = C.c_size_t(0)
+    q = np.zeros(8, np.float32)
+    keys, dists, cnt = np.zeros(4, np.uint64), np.zeros(4, np.float32), np.zeros(1, np.uint32)
+    f32p, u64p, u32p, u8p, u16p = (C.POINTER(t) for t in (C.c_float, C.c_uint64, C.c_uint32, C.c_uint8, C.c_uint16))
+    bm = np.zeros(4, np.uint8)
+    rc = L.leann_backend_search_filtered(None, q.ctypes.data_as(f32p), 4, 16, bm.ctypes.data_as(u8p), keys.ctypes.data_as(u64p),
+                                         dists.ctypes.data_as(f32p), C.byref(n_out))
+    assert rc == 1 and b"null" in L.leann_last_error()
+    rc = L.leann_backend_search_filtered_batch_device(None, None, 1, 4, 16, None, 0, None, None, None, None, None)
+    assert rc == 1
+    rc = L.leann_recompute_search_batch(None, q.ctypes.data_as(f32p), 1, 4, None, keys.ctypes.data_as(u64p), dists.ctypes.data_as(f32p),
+                                        cnt.ctypes.data_as(u32p))
+    assert rc == 1 and b"null" in L.leann_last_error()
+    out = C.c_void_p()
+    F, W = np.zeros((4, 16), np.uint16), np.zeros((16, 8), np.uint16)
+    rc = L.leann_recompute_create_host(F.ctypes.data_as(u16p), 4, 0, W.ctypes.data_as(u16p), 8, 0, 0, C.byref(out))
+    assert rc == 1  # h == 0
+    if la.device_count() == 0:
+        rc = L.leann_recompute_create_host(F.ctypes.data_as(u16p), 4, 16, W.ctypes.data_as(u16p), 8, 0, 0, C.byref(out))
+        assert rc == 4 and b"no CPU fallback" in L.leann_last_error()
