@@ -133,7 +133,7 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
         elapsed = float(tt.item())
     enc_ms, sc_ms, tk_ms = [float(np.mean([t[i] for t in tm])) for i in range(3)]
     # fused kernel: encode GEMM F[N x h] W[h x d] + feature-space scoring F (W Q^T) as three bf16 pieces (hi/lo/lo2)
-    enc_flops, sc_flops = 2.0 * rows * h * d, 3 * 2.0 * rows * h * 64
+    enc_flops, sc_flops = 2.0 * rows * h * d, 3 * 2.0 * rows * h * ((B + 31) // 32 * 32)  # one encode shared by the batch; a G tile per 32 queries
     fused_tf = (enc_flops + sc_flops) / (enc_ms * 1e-3) / 1e12
     roof = {"bound": "mfma", "unit": "TFLOP/s", "traffic": None,
             "kernel": "fused_fstat_kernel<16,true> (bf16 MFMA 32x32x16: encode GEMM + row norms + feature-space scoring + candidate emission, fused)",

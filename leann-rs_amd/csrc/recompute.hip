@@ -125,10 +125,11 @@ __global__ void tile_weights_kernel(const uint16_t *__restrict__ W, uint32_t h, 
 // ------------------------------------------------------------------------------------------------
 __global__ void project_queries_kernel(const uint16_t *__restrict__ W, uint32_t h, uint32_t hp, uint32_t d,
                                        const float *__restrict__ Q, uint32_t ldq, uint32_t nq, uint16_t *__restrict__ Gp,
-                                       int by_query_tile) {
+                                       int by_query_tile, uint32_t q_slots) {
+    // q_slots: query slots of the image (64 for encode_kernel; a multiple of 32 up to FSTAT_MAX_QUERIES for fused_fstat_kernel)
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; // (k, q)
-    if (idx >= hp * 64) return;
-    const uint32_t k = idx / 64, q = idx % 64;
+    if (idx >= hp * q_slots) return;
+    const uint32_t k = idx / q_slots, q = idx % q_slots;
     float g = 0.f;
     if (k < h && q < nq) {
         const uint16_t *wk = W + (size_t)k * d;
@@ -141,7 +142,7 @@ __global__ void project_queries_kernel(const uint16_t *__restrict__ W, uint32_t 
     const float r2 = r1 - __uint_as_float((uint32_t)lo << 16);
     const uint16_t lo2 = f32_to_bf16_rne(r2);
     const uint32_t ks = k / 16, kk = k % 16;
-    uint16_t *base = Gp + (size_t)ks * 192 * 16;
+    uint16_t *base = Gp + (size_t)ks * (q_slots * 3) * 16;
     if (by_query_tile) { // fused_fstat_kernel: Gp[kstep][query tile][piece][32 q][16] — the three pieces of a query tile are contiguous
         base += ((q >> 5) * 96 + (q & 31)) * 16 + kk;
         base[0] = hi;
@@ -430,7 +431,7 @@ static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows,
     const bool fused = Gp != nullptr;
     if (fused && use_fstat(r)) {
         // features stationary in registers (the common shape: h = 256, dims = 384 / 768)
-        const size_t lds2 = 2 * 16 * 128 * 32 + 4 * 128 * 4 + 64 * 4; // two 64-KiB sub-slice buffers + per-wave norm exchange + thresholds
+        const size_t lds2 = 2 * 16 * 128 * 32 + 4 * 64 * 4 + FSTAT_MAX_QUERIES * 4; // two 64-KiB sub-slice buffers + per-wave norm exchange + thresholds
         const uint64_t unit_rows = 4 * LEANN_FSTAT_RB * 32, units = (rows + unit_rows - 1) / unit_rows; // NWV * RB * 32 passages per unit
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device);
@@ -696,8 +697,11 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
             rw->Ft = nullptr;
         }
     }
-    if (int e = grow_scratch((void **)&rw->sS, &rw->capS, sizeof(float) * 64 * chunk)) return e;
-    if (int e = grow_scratch((void **)&rw->sGp, &rw->capGp, r->hp * 192 * 2 + 1024)) return e; // + the fourth (unused) KiB piece of the last k-step
+    // queries per pass over the passages: the encode GEMM is shared by all of them (fused_fstat_kernel: up to 256, one G sub-slice
+    // per 32 queries and unit); the general kernel is built for 64
+    const size_t QT = use_fstat(r) ? FSTAT_MAX_QUERIES : 64;
+    if (int e = grow_scratch((void **)&rw->sS, &rw->capS, sizeof(float) * QT * chunk)) return e;
+    if (int e = grow_scratch((void **)&rw->sGp, &rw->capGp, r->hp * QT * 3 * 2 + 1024)) return e; // + the fourth (unused) KiB piece of the last k-step
     {
         size_t capB = rw->capCand;
         if (int e = grow_scratch((void **)&rw->sCandA, &rw->capCand, sizeof(uint64_t) * nq * cand_len)) return e;
@@ -713,26 +717,28 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     FstatEmit em{};
     uint32_t *d_overflow = nullptr;
     if (emit) {
-        if (int e = grow_scratch((void **)&rw->sEmit, &rw->capEmit, 1024 + sizeof(uint64_t) * 64 * EMIT_CAP)) return e;
+        // [QT f32 thr | QT u32 cnt | u32 overflow | pad to 4 KiB | QT x EMIT_CAP u64 list]
+        if (int e = grow_scratch((void **)&rw->sEmit, &rw->capEmit, 4096 + sizeof(uint64_t) * QT * EMIT_CAP)) return e;
         em.thr = reinterpret_cast<const float *>(rw->sEmit);
-        em.cnt = reinterpret_cast<uint32_t *>(rw->sEmit + 256);
-        d_overflow = reinterpret_cast<uint32_t *>(rw->sEmit + 512);
-        em.list = reinterpret_cast<uint64_t *>(rw->sEmit + 1024);
+        em.cnt = reinterpret_cast<uint32_t *>(rw->sEmit + 1024);
+        d_overflow = reinterpret_cast<uint32_t *>(rw->sEmit + 2048);
+        em.list = reinterpret_cast<uint64_t *>(rw->sEmit + 4096);
         em.cap = EMIT_CAP;
         em.allow = d_allow_mask;
-        HIP_CHECK_RET(hipMemsetAsync(rw->sEmit, 0, 1024, st));
+        HIP_CHECK_RET(hipMemsetAsync(rw->sEmit, 0, 4096, st));
     }
     HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
     HIP_CHECK_RET(hipMemsetAsync(best, 0xFF, sizeof(uint64_t) * nq * k, st));
     int rc = LEANN_OK;
-    const size_t n_tiles = (nq + 63) / 64;
+    const size_t n_tiles = (nq + QT - 1) / QT;
     std::vector<hipEvent_t> evs(n_tiles * n_chunks * 3 + 1);
     for (auto &e : evs) HIP_CHECK_RET(hipEventCreate(&e));
     size_t ei = 0;
-    for (size_t q0 = 0; q0 < nq && rc == LEANN_OK; q0 += 64) {
-        const uint32_t nqt = (uint32_t)std::min<size_t>(64, nq - q0);
-        hipLaunchKernelGGL(project_queries_kernel, dim3((unsigned)((r->hp * 64 + 255) / 256)), dim3(256), 0, st, r->Wraw, (uint32_t)r->h,
-                           (uint32_t)r->hp, (uint32_t)r->d, d_queries + q0 * r->d, (uint32_t)r->d, nqt, Gp, use_fstat(r) ? 1 : 0);
+    for (size_t q0 = 0; q0 < nq && rc == LEANN_OK; q0 += QT) {
+        const uint32_t nqt = (uint32_t)std::min<size_t>(QT, nq - q0);
+        const uint32_t q_slots = use_fstat(r) ? (nqt + 31) / 32 * 32 : 64; // fused_fstat_kernel sizes its G image by 32-query tiles
+        hipLaunchKernelGGL(project_queries_kernel, dim3((unsigned)((r->hp * q_slots + 255) / 256)), dim3(256), 0, st, r->Wraw, (uint32_t)r->h,
+                           (uint32_t)r->hp, (uint32_t)r->d, d_queries + q0 * r->d, (uint32_t)r->d, nqt, Gp, use_fstat(r) ? 1 : 0, q_slots);
         size_t seg_off = 0;
         for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
             const size_t row0 = chunks[c].first, rows = chunks[c].second;
@@ -746,7 +752,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
                 rc = leann_internal_topk_chunk(S, rows, nqt, k, d_allow_mask, row0, candA + q0 * cand_len, cand_len, seg_off, st, &segs,
                                                best + q0 * k);
             if (rc == LEANN_OK && emit) // merge the survivors (none after chunk 0), publish the k-th best as the next threshold
-                hipLaunchKernelGGL(fold_candidates_kernel, dim3(64), dim3(256), 0, st, em.list, em.cnt, em.cap, k, nqt, best + q0 * k,
+                hipLaunchKernelGGL(fold_candidates_kernel, dim3((unsigned)QT), dim3(256), 0, st, em.list, em.cnt, em.cap, k, nqt, best + q0 * k,
                                    const_cast<float *>(em.thr), d_overflow);
             (void)hipEventRecord(evs[ei++], st);
             seg_off += segs;

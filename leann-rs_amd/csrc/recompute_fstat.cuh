@@ -141,13 +141,14 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
 // epilogue compares each score with the query's running k-th best (fixed for the chunk) and appends the few survivors
 // (~k * chunk / rows_seen per query) to a per-query list; fold_candidates_kernel merges them into the running best-k.
 struct FstatEmit {
-    const float *thr;      // [64] score of the running k-th best per query of the tile (+inf: query slot unused); null = write S
-    uint32_t *cnt;         // [64] survivors appended so far (may exceed cap: the list then overflowed)
-    uint64_t *list;        // [64 x cap] keys ~orderable(score) << 32 | position
+    const float *thr;      // [FSTAT_MAX_QUERIES] score of the running k-th best per query (+inf: query slot unused); null = write S
+    uint32_t *cnt;         // [FSTAT_MAX_QUERIES] survivors appended so far (may exceed cap: the list then overflowed)
+    uint64_t *list;        // [FSTAT_MAX_QUERIES x cap] keys ~orderable(score) << 32 | position
     uint32_t cap;
     const uint8_t *allow;  // optional early filter over positions (recompute.rs:66-71)
     uint64_t pos0;         // position of the chunk's first row
 };
+#define FSTAT_MAX_QUERIES 256 // queries per launch: the encode GEMM is shared, each 32-query tile adds one G sub-slice per unit
 #define LEANN_FSTAT_RB 2 // 32-passage blocks per wave (the per-k-step asm statements are written for two)
 // Fragment-major copy of the features for fused_fstat_kernel: Ft[block of 32 rows][k-step][lane = lh * 32 + row][8 bf16], i.e.
 // the 1 KiB a wave loads per (block, k-step) is contiguous (8 full lines per instruction instead of 32 quarter lines of a
@@ -180,11 +181,12 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sbuf = smem;                                     // [2][SUBB]
     float *sNrm = reinterpret_cast<float *>(smem + 2 * SUBB);       // [NWV][RB * 32] sums of squares of a wave's passages
-    float *sThr = sNrm + NWV * RB * 32;                             // [64] emission thresholds of the query tile
+    float *sThr = sNrm + NWV * RB * 32;                             // [FSTAT_MAX_QUERIES] emission thresholds of the launch's queries
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform in an SGPR: DMA addresses stay scalar + lane offset
     const int l31 = lane & 31, lh = lane >> 5;
-    const int nsw = (int)(dp / SUB), nsub = nsw + 2;
+    const int nqt = (int)((nq + 31) / 32);                 // 32-query tiles of this launch (<= FSTAT_MAX_QUERIES / 32)
+    const int nsw = (int)(dp / SUB), nsub = nsw + nqt;
     const uint64_t n_units = (n + UNIT - 1) / UNIT;
 
     // DMA addresses = scalar base (SGPRs) + a 32-bit per-lane offset re-materialised at every use (the opaque asm keeps the
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, ldst, 16, 2048, 0);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, ldst, 16, 3072, 0);
             } else { // query tile j - nsw: pieces hi, lo, lo2 = column tiles 0..2 of the image
-                const char *src = reinterpret_cast<const char *>(Gp) + ((size_t)ks * 192 + (size_t)(j - nsw) * 96) * 32 + vo;
+                const char *src = reinterpret_cast<const char *>(Gp) + ((size_t)ks * nqt * 96 + (size_t)(j - nsw) * 96) * 32 + vo;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, ldst, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, ldst, 16, 1024, 0);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, ldst, 16, 2048, 0);
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     };
 
     if (blockIdx.x >= n_units) return;
-    if (em.thr && tid < 64) sThr[tid] = em.thr[tid]; // visible to every wave long before its first use (a barrier per sub-slice)
+    if (em.thr) sThr[tid] = em.thr[tid]; // 256 threads, FSTAT_MAX_QUERIES = 256 slots; // visible to every wave long before its first use (a barrier per sub-slice)
     // Every workgroup does the same work per unit, so all 256 would fetch their next features in the same few microseconds
     // and queue on HBM (~14 000 cycles per unit).  On long launches the workgroups of an XCD start 1/8 of a unit apart.
     if (n_units >= 8ull * gridDim.x) {
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
             const bool nw = jn < nsw;
             const char *dbase = nw ? reinterpret_cast<const char *>(Wp) + (size_t)jn * (SUB * 32)
                                    : reinterpret_cast<const char *>(Gp) + (size_t)(jn - nsw) * (96 * 32);
-            const uint32_t dstride = nw ? dp * 32 : 192 * 32; // bytes between k-steps of the source image
+            const uint32_t dstride = nw ? dp * 32 : (uint32_t)nqt * (96 * 32); // bytes between k-steps of the source image
             const char *dsb[4];
             uint32_t dld[4];
 #pragma unroll
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 }
             } else {
                 const int qt = j - nsw;
-                // last sub-slice of the unit (qt == 1): each feature register is refilled for the next unit right after its last
+                // last sub-slice of the unit (the last query tile): each feature register is refilled for the next unit right after its last
                 // use; unconditional (the last unit re-reads its own rows) so that no branch or register copy sits between MFMAs
                 const uint64_t nprow0 = (last_unit ? unit : next_unit) * UNIT + (uint64_t)wave * (RB * 32);
                 f32x16 sc[RB];
@@ -422,7 +424,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                         if constexpr (PF && piece == 2) load_features(a, nprow0, ks);
                     });
                 };
-                if (qt == 1) g_loop(std::true_type{});
+                if (qt == nqt - 1) g_loop(std::true_type{});
                 else g_loop(std::false_type{});
                 asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1])); // as above: no reader of the score tiles above the pad
 #ifdef LEANN_STAMPS

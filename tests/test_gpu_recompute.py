@@ -47,7 +47,8 @@ def test_encode_matches_oracle(la, po, gpu, n, h, d):
 
 
 @pytest.mark.parametrize("n,h,d,nq,k", [(6000, 256, 768, 70, 10), (2500, 64, 128, 5, 3), (4100, 128, 256, 64, 16),
-                                        (4500, 256, 384, 33, 5), (5000, 256, 512, 64, 12), (4200, 256, 600, 3, 10), (300, 256, 768, 2, 10)])
+                                        (4500, 256, 384, 33, 5), (5000, 256, 512, 64, 12), (4200, 256, 600, 3, 10), (300, 256, 768, 2, 10),
+                                        (5000, 256, 768, 200, 10), (4800, 256, 768, 300, 4)])
 def test_recompute_search_matches_restatement(la, po, gpu, n, h, d, nq, k):
     L, chk, F, W, Q, r, keep = _mk(la, po, n, h, d, nq)
     dQ = la.DeviceArray.from_host(Q)
@@ -189,7 +190,7 @@ def test_multi_chunk_candidate_emission(la, po, gpu, monkeypatch):
     """> 128k passages: chunks after the first emit their few survivors straight from the fused kernel (no score slab).
     Must equal the slab path bit for bit (same kernel arithmetic), agree with the general kernel within 1e-5, and honour
     the allow mask; spot-checked against the oracle restatement on the winners."""
-    n, h, d, nq, k = 700000, 256, 768, 70, 10
+    n, h, d, nq, k = 700000, 256, 768, 150, 10
     L, chk = la.lib(), la._native.check
     dF, dW = la.DeviceArray((n, h), np.uint16), la.DeviceArray((h, d), np.uint16)
     chk(L.leann_synth_features_device(SEED, h, 64, 4096, 1.0, 0, 0, n, dF.ptr, None))
@@ -219,7 +220,7 @@ def test_multi_chunk_candidate_emission(la, po, gpu, monkeypatch):
     monkeypatch.delenv("LEANN_RECOMPUTE_NO_TILED")
     # oracle on the winners: score = <l2norm(W^T f), q>  (recompute.rs:96-103)
     F = dF.to_host()
-    for i in (0, 33, 69):
+    for i in (0, 33, 69, 149):
         pos = (gk[i] - 5000).astype(np.int64)
         E = po.recompute_encode(F[pos], W)
         assert np.abs(E @ Q[i] - gs[i]).max() <= 1e-5
