@@ -94,7 +94,8 @@ void leann_backend_close(leann_backend *h);
 int leann_backend_build(int backend, const float *vectors, size_t n, size_t dims,
                         size_t graph_degree, size_t complexity, const char *index_path_stem);
 /* BackendBuilder::add_to_index(embeddings, index_path, dims, start_id)  mod.rs:82-100,
- * hnsw.rs:142-191.  DiskANN -> LEANN_ERR_UNSUPPORTED with the reference's message. */
+ * hnsw.rs:142-191: appends to the index on disk (the new rows continue the insertion from the loaded graph; cost
+ * proportional to the rows added).  DiskANN -> LEANN_ERR_UNSUPPORTED with the reference's message. */
 int leann_backend_add(int backend, const float *vectors, size_t n, size_t dims, size_t start_id,
                       const char *index_path_stem);
 

@@ -345,6 +345,33 @@ __global__ void col_mean_kernel(const double *__restrict__ part, size_t n, uint3
     mean[j] = (float)(s / (double)n);
 }
 
+// Stored link distances of an existing graph (the index file does not carry them): one wave per node walks its level-0
+// list and its upper lists and recomputes dist(node, neighbour) with the canonical wave dot — bit-identical to the value
+// the construction search produced when the link was made (fmaf is symmetric in its factors), so an append continues
+// exactly from the state a one-shot build would have had.
+__global__ void __launch_bounds__(256) link_dist_kernel(const float *__restrict__ X, uint32_t ld, ListView lv,
+                                                        const uint8_t *__restrict__ levels, uint32_t n_nodes) {
+    const uint32_t node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (node >= n_nodes) return;
+    const float *xi = X + (size_t)node * ld;
+    const int T = (int)((ld + 255) / 256);
+    const uint32_t top = levels[node];
+    for (uint32_t level = 0; level <= top; level++) {
+        uint32_t *ids; float *ds; uint32_t cap;
+        list_ptr(lv, node, level, &ids, &ds, &cap);
+        for (uint32_t j = 0; j < cap; j++) {
+            const uint32_t e = ids[j];
+            if (e == LEANN_EMPTY) break; // lists are compact
+            const float *xe = X + (size_t)e * ld;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < T; t++) fma4(acc, row_load4(xi, ld, t, lane), row_load4(xe, ld, t, lane));
+            const float d = 1.0f - wave_tree_sum(lane4_sum(acc));
+            if (lane == 0) ds[j] = d;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct Builder {
     leann_backend *h;
@@ -556,8 +583,10 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
         s0 = 1;
     } else {
         hipLaunchKernelGGL(iota_skip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b.st, b.d_order, n, 0u);
-        // existing links carry no stored distances: recompute lazily is not needed — appended points
-        // only ever prune lists through reverse_merge_kernel, which reads adjd; fill them now.
+        // append: the existing links' stored distances (read by reverse_merge_kernel when a list is pruned)
+        hipLaunchKernelGGL(link_dist_kernel, dim3((unsigned)((n_existing + 3) / 4)), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, h->d_levels,
+                           (uint32_t)n_existing);
+        BCHECK(hipGetLastError());
     }
     size_t bmax = bmax_hint ? bmax_hint : 16384;
     rc = builder_alloc_scratch(b, bmax);
@@ -701,9 +730,11 @@ extern "C" int leann_backend_add(int backend, const float *vectors, size_t n, si
         leann_backend_close(old);
         return LEANN_ERR_INVALID;
     }
-    // Rebuild over old rows + new rows.  (Batched insertion continues from an existing graph only with
-    // stored link distances, which the file does not carry; a full rebuild keeps the result identical
-    // to building the concatenation in one go.)
+    // Append: the new rows continue the batched insertion from the existing graph (hnsw.rs:142-191 adds to the loaded index).
+    // Levels are a hash of the position, so the first n_old nodes keep their upper-list offsets; the stored link distances
+    // the builder prunes with are recomputed (link_dist_kernel).  Equal to a one-shot build of the concatenation whenever
+    // the batch boundaries coincide (n_old a power of two <= 16 384 or a multiple of 16 384); otherwise the same algorithm
+    // on a different batch schedule.
     const size_t ld = old->g.ld, nt = n_old + n;
     float *dX = nullptr;
     BCHECK(hipMalloc((void **)&dX, std::max<size_t>(nt * ld, 4) * 4));
@@ -712,11 +743,55 @@ extern "C" int leann_backend_add(int backend, const float *vectors, size_t n, si
         BCHECK(hipMemset(dX + n_old * ld, 0, n * ld * 4));
         BCHECK(hipMemcpy2D(dX + n_old * ld, ld * 4, vectors, dims * 4, dims * 4, n, hipMemcpyHostToDevice));
     }
-    const size_t M = old->g.M, efc = old->efc;
+    leann_backend *h = new leann_backend();
+    h->kind = backend;
+    h->device = old->device;
+    h->key_offset = old->key_offset;
+    h->efc = old->efc;
+    h->alpha = old->alpha;
+    h->g = old->g;
+    h->g.X = dX;
+    h->g.n = nt;
+    h->g.adj0 = nullptr; h->g.adjU = nullptr; h->g.upper_off = nullptr;
+    h->owns_rows = true;
+    rc = alloc_graph_arrays(h, LEVEL_SEED);
+    bool same_levels = true; // an index that did not come from this builder (leann_backend_from_arrays + save) has its own level table
+    if (rc == LEANN_OK && n_old) {
+        std::vector<uint8_t> la(n_old), lb(n_old);
+        if (hipMemcpy(la.data(), old->d_levels, n_old, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(lb.data(), h->d_levels, n_old, hipMemcpyDeviceToHost) != hipSuccess) {
+            leann_set_error("add_to_index: reading the level tables failed");
+            rc = LEANN_ERR_DEVICE;
+        } else {
+            same_levels = la == lb;
+        }
+    }
+    if (rc == LEANN_OK && !same_levels) { // foreign level table: rebuild over the concatenation (the pre-append behaviour)
+        const size_t M = old->g.M, efc = old->efc;
+        leann_backend_close(old);
+        h->g.X = nullptr;
+        h->owns_rows = false;
+        leann_backend_close(h);
+        rc = leann_backend_build_device(backend, dX, nt, dims, ld, M, efc, 0, 0, 0, &h);
+        if (rc) { (void)hipFree(dX); return rc; }
+        h->owns_rows = true;
+        rc = leann_backend_save(h, index_path_stem);
+        leann_backend_close(h);
+        return rc;
+    }
+    if (rc == LEANN_OK && n_old) {
+        if (hipMemcpy(const_cast<uint32_t *>(h->g.adj0), old->g.adj0, n_old * h->g.M0 * 4, hipMemcpyDeviceToDevice) != hipSuccess ||
+            (old->n_upper_lists && hipMemcpy(const_cast<uint32_t *>(h->g.adjU), old->g.adjU, old->n_upper_lists * h->g.M * 4,
+                                             hipMemcpyDeviceToDevice) != hipSuccess)) {
+            leann_set_error("add_to_index: copying the existing graph failed");
+            rc = LEANN_ERR_DEVICE;
+        }
+    }
+    const size_t old_lists = old->n_upper_lists;
     leann_backend_close(old);
-    leann_backend *h = nullptr;
-    rc = leann_backend_build_device(backend, dX, nt, dims, ld, M, efc, 0, 0, 0, &h);
-    if (rc) { (void)hipFree(dX); return rc; }
+    if (rc == LEANN_OK && old_lists > h->n_upper_lists) { leann_set_error("add_to_index: inconsistent level table"); rc = LEANN_ERR_INVALID; }
+    if (rc == LEANN_OK && n) rc = build_on_device(h, n_old, 0);
+    if (rc) { leann_backend_close(h); return rc; }
     h->owns_rows = true;
     rc = leann_backend_save(h, index_path_stem);
     leann_backend_close(h);

@@ -86,24 +86,55 @@ def test_degenerate_sizes(la, po, gpu, tmp_path):
 
 
 def test_add_to_index_equals_one_shot_build(la, po, gpu, tmp_path):
-    n0, n1, d = 4000, 2500, 64
-    X = synth(po, n0 + n1, d)
+    """add_to_index appends to the loaded graph (hnsw.rs:142-191): the new rows continue the batched insertion from the saved state
+    (stored link distances recomputed).  With coinciding batch boundaries (n0 a power of two) the result is the one-shot graph,
+    bit for bit; otherwise it is the same algorithm on another batch schedule: invariants + recall."""
+    d = 64
     Q = synth(po, 100, d, stream=1)
-    a, b = tmp_path / "a", tmp_path / "b"
-    a.mkdir(); b.mkdir()
     B = la.BackendBuilder(la.BackendType.Hnsw)
-    B.build(X[:n0], [], str(a / "documents.leann"), d, 12, 48)
-    with pytest.raises(la.LeannError, match="does not continue"):
-        B.add_to_index(X[n0:], str(a / "documents.leann"), d, n0 + 5)
-    B.add_to_index(X[n0:], str(a / "documents.leann"), d, n0)  # hnsw.rs:142-191: ids continue at start_id
-    B.build(X, [], str(b / "documents.leann"), d, 12, 48)
-    sa, sb = la.HnswSearcher.load(str(a / "documents.leann"), d), la.HnswSearcher.load(str(b / "documents.leann"), d)
-    assert sa.len() == n0 + n1
-    ka, da, _ = sa.search_batch(Q, 10, 64)
-    kb, db, _ = sb.search_batch(Q, 10, 64)
-    assert (ka == kb).all() and (da == db).all()
-    assert recall_at_k(ka, po.exact_topk(X, Q, 10)) >= 0.95
-    sa.close(); sb.close()
+    for case, (n0, n1) in enumerate(((4096, 2500), (4000, 2500), (300, 40000))):
+        X = synth(po, n0 + n1, d)
+        a, b = tmp_path / f"a{case}", tmp_path / f"b{case}"
+        a.mkdir(); b.mkdir()
+        B.build(X[:n0], [], str(a / "documents.leann"), d, 12, 48)
+        with pytest.raises(la.LeannError, match="does not continue"):
+            B.add_to_index(X[n0:], str(a / "documents.leann"), d, n0 + 5)
+        B.add_to_index(X[n0:], str(a / "documents.leann"), d, n0)  # ids continue at start_id
+        B.build(X, [], str(b / "documents.leann"), d, 12, 48)
+        sa, sb = la.HnswSearcher.load(str(a / "documents.leann"), d), la.HnswSearcher.load(str(b / "documents.leann"), d)
+        assert sa.len() == n0 + n1
+        ga, gb = sa.graph_export(with_vectors=True), sb.graph_export()
+        assert (ga["vectors"] == X).all() and (ga["levels"] == gb["levels"]).all()
+        ka, da, _ = sa.search_batch(Q, 10, 64)
+        kb, db, _ = sb.search_batch(Q, 10, 64)
+        truth = po.exact_topk(X, Q, 10)
+        if case == 0:
+            assert (ga["adj0"] == gb["adj0"]).all() and (ga["adjU"] == gb["adjU"]).all() and ga["entry"] == gb["entry"]
+            assert (ka == kb).all() and (da == db).all()
+        else:
+            a0 = ga["adj0"]
+            valid = a0 != 0xFFFFFFFF
+            assert (a0[valid] < n0 + n1).all() and valid.sum(1).min() >= 1
+            assert (valid[:, :-1] >= valid[:, 1:]).all()  # compact lists
+            assert abs(recall_at_k(ka, truth) - recall_at_k(kb, truth)) <= 0.02
+        assert recall_at_k(ka, truth) >= 0.95
+        sa.close(); sb.close()
+    # an index whose level table did not come from this builder (oracle graph saved through from_arrays): rebuilt on append
+    n0, n1 = 1500, 500
+    X = synth(po, n0 + n1, d)
+    G = po.Graph.build_hnsw(X[:n0], M=8, efc=32)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X[:n0], 8, 16, G.max_level, G.entry, lv, uo, a0, aU)
+    c = tmp_path / "c"
+    c.mkdir()
+    s.save(str(c / "documents.leann"))
+    s.close()
+    B.add_to_index(X[n0:], str(c / "documents.leann"), d, n0)
+    sc = la.HnswSearcher.load(str(c / "documents.leann"), d)
+    assert sc.len() == n0 + n1
+    kc, _, _ = sc.search_batch(Q, 10, 64)
+    assert recall_at_k(kc, po.exact_topk(X, Q, 10)) >= 0.9
+    sc.close()
 
 
 def test_build_is_reproducible(la, po, gpu):
