@@ -366,20 +366,29 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 stCW += tN - tB;
 #endif
                 if (j == nsw - 1) { // all columns seen: flush the last tile, then row norms (candle.rs:218-225)
+                    // sum over the 32 lanes of a half wave by DPP row shifts (__shfl_xor is an LDS permute: 160 of them cost
+                    // ~14 000 cycles per unit here); the totals land in lanes 31 and 63.  Step-major over the 16 values of a block:
+                    // independent chains, no hazard nop between a value's dependent DPP steps.
 #pragma unroll
-                    for (int rb = 0; rb < RB; rb++)
+                    for (int rb = 0; rb < RB; rb++) {
+                        float p[16];
 #pragma unroll
-                        for (int reg = 0; reg < 16; reg++) {
-                            // sum over the 32 lanes of a half wave by DPP row shifts (__shfl_xor is an LDS permute: 160 of them
-                            // cost ~14 000 cycles per unit here); the totals land in lanes 31 and 63
-                            float p = fmaf(accB[rb][reg], accB[rb][reg], ssq[rb][reg]);
-                            p = dpp_add(p, 0x111, 0xf); // row_shr:1
-                            p = dpp_add(p, 0x112, 0xf); // row_shr:2
-                            p = dpp_add(p, 0x114, 0xf); // row_shr:4
-                            p = dpp_add(p, 0x118, 0xf); // row_shr:8  -> lane 15 of each row of 16 holds the row total
-                            p = dpp_add(p, 0x142, 0xa); // row_bcast:15 into rows 1 and 3
-                            if (l31 == 31) sNrm[wave * (RB * 32) + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh] = p;
+                        for (int reg = 0; reg < 16; reg++) p[reg] = fmaf(accB[rb][reg], accB[rb][reg], ssq[rb][reg]);
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x111, 0xf); // row_shr:1
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x112, 0xf); // row_shr:2
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x114, 0xf); // row_shr:4
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x118, 0xf); // row_shr:8 -> lane 15 of each row of 16 = row total
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x142, 0xa); // row_bcast:15 into rows 1 and 3
+                        if (l31 == 31) {
+#pragma unroll
+                            for (int reg = 0; reg < 16; reg++) sNrm[wave * (RB * 32) + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh] = p[reg];
                         }
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
