@@ -48,6 +48,9 @@ WORKLOADS = {
     # configs[2] with the LEANN idea proper: HNSW whose distances are recomputed from the bf16 features (no stored vectors)
     "recompute10m_graph": dict(rows=10_000_000, d=768, h=256, M=32, efc=200, ef=128, kind="recompute_graph"),
     "recompute1m_graph": dict(rows=1_000_000, d=768, h=256, M=32, efc=200, ef=128, kind="recompute_graph"),
+    # SURVEY 8(d) "brute-force scan": exact search over stored f32 rows (RecomputeSearcher's dot + sort + take over materialised
+    # embeddings, recompute.rs:96-109; also every workload's ground truth), batch 64
+    "scan10m": dict(rows=10_000_000, d=768, kind="scan", batch=64),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = f32 vector peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
@@ -190,6 +193,64 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
         dist.destroy_process_group()
 
 
+def bench_scan(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log):
+    """Exact scan: one step = one batch of 64 queries against all `rows` stored f32 rows (score_mfma_kernel on the f32 matrix
+    cores, k-ordered chains = bit-exact with the oracle's sequential fmaf dot, + segment top-k).  Replicas only for N > 1."""
+    rows, d = wl["rows"], wl["d"]
+    B = wl["batch"] if args.batch == 16384 else args.batch
+    k, ld = args.k, (d + 3) // 4 * 4
+    steps, warmup = min(args.steps, 10), min(args.warmup, 2)
+    stream = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(stream.cuda_stream)
+    X = torch.empty((rows, ld), dtype=torch.float32, device=dev)
+    Q = torch.empty((B * 4, ld), dtype=torch.float32, device=dev)
+    chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 0, 0, rows, X.data_ptr(), sp))
+    chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 1, rank * B * 4, B * 4, Q.data_ptr(), sp))
+    stream.synchronize()
+    keys = torch.empty((B, k), dtype=torch.int64, device=dev)
+    scores = torch.empty((B, k), dtype=torch.float32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+
+    def step(i):
+        chk(L.leann_scan_topk_device(X.data_ptr(), rows, d, ld, Q.data_ptr() + (i % 4) * B * ld * 4, B, k, None, 0, keys.data_ptr(),
+                                     scores.data_ptr(), counts.data_ptr(), sp))
+    for w in range(warmup):
+        step(w)
+    stream.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        step(s_)
+    stream.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    step_s = elapsed / steps
+    nbytes, flops = rows * d * 4.0, 2.0 * rows * d * B
+    out = {"metric": "queries/sec @ recall@10>=0.95", "value": B * steps * world / elapsed, "unit": "queries/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "recall_at_10": 1.0,
+           "config": {"workload": f"{args.workload}: exact scan of {rows} x {d} stored f32 rows per GPU, batch {B} queries/step, top-{k}",
+                      "rows_per_gpu": rows, "dims": d, "batch": B, "top_k": k, "parallelism": "single" if world == 1 else f"replica{world}"},
+           "roofline": {"bound": "hbm", "achieved": nbytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": nbytes / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "score_mfma_kernel (+ topk_scores_kernel)",
+                        "algorithmic_bytes_per_step": nbytes, "f32_mfma_tflops": flops / step_s / 1e12,
+                        "f32_mfma_frac": flops / step_s / 1e12 / F32_MFMA_PEAK_TFLOPS}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +303,8 @@ def main():
             print("[bench]", *a, file=sys.stderr, flush=True)
 
     wl = dict(WORKLOADS[args.workload])
+    if wl.get("kind") == "scan":
+        return bench_scan(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log)
     if wl.get("kind") == "recompute":
         return bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log)
     rows, d, M, efc = wl["rows"], wl["d"], wl["M"], wl["efc"]

@@ -41,6 +41,21 @@ struct leann_backend {
 };
 
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st);
+
+// Candidate emission of the exhaustive searches (recompute_fstat.cuh, scan.hip): instead of writing an nq x rows score slab for a
+// separate top-k pass, a scoring kernel compares each score with the query's running k-th best (fixed for the launch) and appends
+// the few survivors (~k * rows / rows_seen per query) to a per-query list; leann_internal_fold_candidates merges the lists into the
+// running best-k (ascending keys ~orderable(score) << 32 | position), publishes the new thresholds and resets the counters.
+struct CandEmit {
+    const float *thr;      // [slots] score of the running k-th best per query (+inf: query slot unused); null = the kernel writes its slab
+    uint32_t *cnt;         // [slots] survivors appended so far (may exceed cap: the list then overflowed)
+    uint64_t *list;        // [slots x cap] keys
+    uint32_t cap;
+    const uint8_t *allow;  // optional early filter over positions (recompute.rs:66-71)
+    uint64_t pos0;         // position of the launch's first row
+};
+int leann_internal_fold_candidates(const CandEmit &em, uint32_t k, uint32_t nq, uint32_t slots, uint64_t *best, uint32_t *d_overflow,
+                                   hipStream_t st);
 int leann_internal_score(const float *X, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t ldq, float *S,
                          hipStream_t st);
 void leann_internal_free_graph(leann_backend *h);

@@ -21,7 +21,7 @@
 #include "common.cuh"
 #include "../../include/leann_backend.h"
 #include "internal.h"
-#include "recompute_fstat.cuh" // fused_fstat_kernel, tile_features_kernel, fold_candidates_kernel, FstatEmit; bf16x8 / f32x16
+#include "recompute_fstat.cuh" // fused_fstat_kernel, tile_features_kernel; bf16x8 / f32x16
 #include <algorithm>
 #include <mutex>
 #include <utility>
@@ -427,7 +427,7 @@ static bool use_fstat(const leann_recompute *r) {
 
 static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st,
                          const uint16_t *Gp = nullptr, uint32_t nq = 0, float *S = nullptr, float *norms = nullptr,
-                         const FstatEmit *emit = nullptr) {
+                         const CandEmit *emit = nullptr) {
     const bool fused = Gp != nullptr;
     if (fused && use_fstat(r)) {
         // features stationary in registers (the common shape: h = 256, dims = 384 / 768)
@@ -440,11 +440,11 @@ static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows,
             HIP_CHECK_RET(hipFuncSetAttribute((const void *)fused_fstat_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL((fused_fstat_kernel<16, true>), dim3(grid2), dim3(256), lds2, st,
                                reinterpret_cast<const uint16_t *>(r->Ft) + row0 * r->h, (uint64_t)rows, r->Wp, (uint32_t)r->dp, Gp, nq, S,
-                               (uint32_t)rows, emit ? *emit : FstatEmit{});
+                               (uint32_t)rows, emit ? *emit : CandEmit{});
         } else {
             HIP_CHECK_RET(hipFuncSetAttribute((const void *)fused_fstat_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL((fused_fstat_kernel<16, false>), dim3(grid2), dim3(256), lds2, st, r->F + row0 * r->h, (uint64_t)rows, r->Wp,
-                               (uint32_t)r->dp, Gp, nq, S, (uint32_t)rows, emit ? *emit : FstatEmit{});
+                               (uint32_t)r->dp, Gp, nq, S, (uint32_t)rows, emit ? *emit : CandEmit{});
         }
         HIP_CHECK_RET(hipGetLastError());
         return LEANN_OK;
@@ -714,7 +714,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     // chunks after the first emit their few survivors straight from the fused kernel (no score slab, no segment sort)
     const uint32_t EMIT_CAP = 8192;
     const bool emit = emit_ok && use_fstat(r) && n_chunks > 1 && k <= 1024 && !getenv("LEANN_DEBUG_NO_EMIT");
-    FstatEmit em{};
+    CandEmit em{};
     uint32_t *d_overflow = nullptr;
     if (emit) {
         // [QT f32 thr | QT u32 cnt | u32 overflow | pad to 4 KiB | QT x EMIT_CAP u64 list]
@@ -752,8 +752,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
                 rc = leann_internal_topk_chunk(S, rows, nqt, k, d_allow_mask, row0, candA + q0 * cand_len, cand_len, seg_off, st, &segs,
                                                best + q0 * k);
             if (rc == LEANN_OK && emit) // merge the survivors (none after chunk 0), publish the k-th best as the next threshold
-                hipLaunchKernelGGL(fold_candidates_kernel, dim3((unsigned)QT), dim3(256), 0, st, em.list, em.cnt, em.cap, k, nqt, best + q0 * k,
-                                   const_cast<float *>(em.thr), d_overflow);
+                rc = leann_internal_fold_candidates(em, k, nqt, (uint32_t)QT, best + q0 * k, d_overflow, st);
             (void)hipEventRecord(evs[ei++], st);
             seg_off += segs;
         }

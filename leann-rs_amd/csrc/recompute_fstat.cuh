@@ -6,6 +6,7 @@
 // src/embedding/candle.rs:165,218-225.  scripts/check_fstat_asm.py guards the hand-counted LDS reads (CPU test).
 #pragma once
 #include "common.cuh"
+#include "internal.h"
 #include <utility>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -137,17 +138,7 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
 #define FSTAT_G_NR(c0, c1, a0, a1, g, cnt)                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(%5)\n\t" FSTAT_MM "%0, %2, %3, %0\n\t" FSTAT_MM "%1, %2, %4, %1"                         \
                  : "+v"(c0), "+v"(c1), "+v"(g) : "a"(a0), "a"(a1), "i"(cnt) : "memory")
-// Candidate emission (chunks after the first): instead of writing the 64 x rows score slab for a separate top-k pass, the
-// epilogue compares each score with the query's running k-th best (fixed for the chunk) and appends the few survivors
-// (~k * chunk / rows_seen per query) to a per-query list; fold_candidates_kernel merges them into the running best-k.
-struct FstatEmit {
-    const float *thr;      // [FSTAT_MAX_QUERIES] score of the running k-th best per query (+inf: query slot unused); null = write S
-    uint32_t *cnt;         // [FSTAT_MAX_QUERIES] survivors appended so far (may exceed cap: the list then overflowed)
-    uint64_t *list;        // [FSTAT_MAX_QUERIES x cap] keys ~orderable(score) << 32 | position
-    uint32_t cap;
-    const uint8_t *allow;  // optional early filter over positions (recompute.rs:66-71)
-    uint64_t pos0;         // position of the chunk's first row
-};
+// Candidate emission (chunks after the first): CandEmit, internal.h.
 #define FSTAT_MAX_QUERIES 256 // queries per launch: the encode GEMM is shared, each 32-query tile adds one G sub-slice per unit
 #define LEANN_FSTAT_RB 2 // 32-passage blocks per wave (the per-k-step asm statements are written for two)
 // Fragment-major copy of the features for fused_fstat_kernel: Ft[block of 32 rows][k-step][lane = lh * 32 + row][8 bf16], i.e.
@@ -170,7 +161,7 @@ __global__ void tile_features_kernel(const uint16_t *__restrict__ F, uint64_t n,
 template <int KS, bool TILED>
 __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__restrict__ F, uint64_t n, const uint16_t *__restrict__ Wp,
                                                           uint32_t dp, const uint16_t *__restrict__ Gp, uint32_t nq,
-                                                          float *__restrict__ S, uint32_t n_rows_s, FstatEmit em) {
+                                                          float *__restrict__ S, uint32_t n_rows_s, CandEmit em) {
     constexpr int NWV = 4, RB = LEANN_FSTAT_RB; // waves per workgroup, 32-passage blocks per wave
     constexpr int SUB = 128;             // columns per W sub-slice (4 MFMA tiles)
     constexpr int KSB = SUB * 32;        // bytes of one k-step of a sub-slice (4 KiB)
@@ -514,40 +505,3 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     }
 #endif
 }
-
-// Merge a chunk's emitted candidates into the running best-k of each query (ascending keys), publish the new k-th best score
-// as the next chunk's threshold, reset the counters.  One workgroup per query slot of the tile (64).
-__global__ void __launch_bounds__(256) fold_candidates_kernel(uint64_t *__restrict__ list, uint32_t *__restrict__ cnt, uint32_t cap,
-                                                              uint32_t k, uint32_t nq, uint64_t *__restrict__ best, float *__restrict__ thr,
-                                                              uint32_t *__restrict__ overflow) {
-    __shared__ uint64_t keys[SEG];
-    const uint32_t q = blockIdx.x;
-    if (q >= nq) { // unused query slot of the tile: never emits
-        if (threadIdx.x == 0) { thr[q] = __uint_as_float(0x7F800000u); cnt[q] = 0; }
-        return;
-    }
-    uint32_t m = cnt[q];
-    if (m > cap) { // the list overflowed: the caller repeats the search on the slab path
-        if (threadIdx.x == 0) atomicAdd(overflow, 1u);
-        m = cap;
-    }
-    const uint64_t *src = list + (size_t)q * cap;
-    if (m) {
-        for (int i = threadIdx.x; i < (int)k; i += blockDim.x) keys[i] = best[(size_t)q * k + i];
-        for (uint32_t base = 0; base < m; base += SEG - k) {
-            for (int i = threadIdx.x; i < SEG - (int)k; i += blockDim.x) {
-                const uint32_t p = base + i;
-                keys[k + i] = p < m ? src[p] : ~0ull;
-            }
-            bitonic_sort_lds(keys, SEG);
-        }
-        for (int i = threadIdx.x; i < (int)k; i += blockDim.x) best[(size_t)q * k + i] = keys[i];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const uint64_t kth = best[(size_t)q * k + (k - 1)];
-        thr[q] = kth == ~0ull ? __uint_as_float(0xFF800000u) : orderable_f32(~(uint32_t)(kth >> 32)); // fewer than k so far: -inf
-        cnt[q] = 0;
-    }
-}
-

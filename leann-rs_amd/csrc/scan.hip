@@ -15,7 +15,10 @@
 //   merge_topk_kernel   G-way merge of per-shard lists by (dist, key) — SURVEY.md §8e.
 #include "common.cuh"
 #include "../../include/leann_backend.h"
+#include "search.cuh"
+#include "internal.h"
 #include <algorithm>
+#include <vector>
 
 
 // ------------------------------------------------------------------------------------------------
@@ -31,7 +34,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 __global__ void __launch_bounds__(256) score_mfma_kernel(const float *__restrict__ X, uint64_t n, uint32_t d,
                                                          uint32_t ld, const float *__restrict__ Q, uint32_t nq,
                                                          uint32_t ldq, uint64_t row0, uint32_t n_rows,
-                                                         float *__restrict__ S /* [nq x n_rows] */) {
+                                                         float *__restrict__ S /* [nq x n_rows] */, CandEmit em = CandEmit{}) {
     constexpr int BR = 128, BQ = 64, BK = 32;
     __shared__ float sX[BK][BR + 4]; // [k][row]
     __shared__ float sQ[BK][BQ + 4]; // [k][query]
@@ -84,6 +87,34 @@ __global__ void __launch_bounds__(256) score_mfma_kernel(const float *__restrict
     }
     // C/D layout: col = lane & 31 (row of X), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
     const uint32_t row = rbase + wave * 32 + l31;
+    if (em.thr) { // candidate emission (CandEmit, internal.h): only the scores that reach their query's running k-th best leave the kernel
+        bool any = false;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const uint32_t qoff = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            any |= acc0[reg] >= em.thr[qbase + qoff];          // thr has a slot (+inf) for every query of the last, partial tile
+            any |= acc1[reg] >= em.thr[qbase + 32 + qoff];
+        }
+        if (any && row < n_rows) {
+            const uint64_t pos = em.pos0 + row;
+            if (!em.allow || ((em.allow[pos >> 3] >> (pos & 7)) & 1)) {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const uint32_t qoff = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const uint32_t q = qbase + half * 32 + qoff;
+                        const float sv = half ? acc1[reg] : acc0[reg];
+                        if (sv >= em.thr[q]) {
+                            const uint32_t slot = atomicAdd(&em.cnt[q], 1u);
+                            if (slot < em.cap) em.list[(size_t)q * em.cap + slot] = ((uint64_t)(~f32_orderable(sv)) << 32) | (uint32_t)pos;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (row < n_rows) {
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
@@ -93,6 +124,49 @@ __global__ void __launch_bounds__(256) score_mfma_kernel(const float *__restrict
             if (q1 < nq) S[(size_t)q1 * n_rows + row] = acc1[reg];
         }
     }
+}
+
+// Merge a launch's emitted candidates into the running best-k of each query (ascending keys), publish the new k-th best score as the
+// next threshold, reset the counters.  One workgroup per query slot.
+__global__ void __launch_bounds__(256) fold_candidates_kernel(uint64_t *__restrict__ list, uint32_t *__restrict__ cnt, uint32_t cap,
+                                                              uint32_t k, uint32_t nq, uint64_t *__restrict__ best, float *__restrict__ thr,
+                                                              uint32_t *__restrict__ overflow) {
+    __shared__ uint64_t keys[SEG];
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) { // unused query slot: never emits
+        if (threadIdx.x == 0) { thr[q] = __uint_as_float(0x7F800000u); cnt[q] = 0; }
+        return;
+    }
+    uint32_t m = cnt[q];
+    if (m > cap) { // the list overflowed: the caller repeats the search on the slab path
+        if (threadIdx.x == 0) atomicAdd(overflow, 1u);
+        m = cap;
+    }
+    const uint64_t *src = list + (size_t)q * cap;
+    if (m) {
+        for (int i = threadIdx.x; i < (int)k; i += blockDim.x) keys[i] = best[(size_t)q * k + i];
+        for (uint32_t base = 0; base < m; base += SEG - k) {
+            for (int i = threadIdx.x; i < SEG - (int)k; i += blockDim.x) {
+                const uint32_t p = base + i;
+                keys[k + i] = p < m ? src[p] : ~0ull;
+            }
+            bitonic_sort_lds(keys, SEG);
+        }
+        for (int i = threadIdx.x; i < (int)k; i += blockDim.x) best[(size_t)q * k + i] = keys[i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t kth = best[(size_t)q * k + (k - 1)];
+        thr[q] = kth == ~0ull ? __uint_as_float(0xFF800000u) : orderable_f32(~(uint32_t)(kth >> 32)); // fewer than k so far: -inf
+        cnt[q] = 0;
+    }
+}
+int leann_internal_fold_candidates(const CandEmit &em, uint32_t k, uint32_t nq, uint32_t slots, uint64_t *best, uint32_t *d_overflow,
+                                   hipStream_t st) {
+    hipLaunchKernelGGL(fold_candidates_kernel, dim3(slots), dim3(256), 0, st, em.list, em.cnt, em.cap, k, nq, best, const_cast<float *>(em.thr),
+                       d_overflow);
+    HIP_CHECK_RET(hipGetLastError());
+    return LEANN_OK;
 }
 
 // scores S[q][n_rows] -> cand[q][seg][k]; key = ~orderable(score) << 32 | (row0 + row)   (position < 2^32)
@@ -259,40 +333,87 @@ extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims
     if (nq == 0) return LEANN_OK;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t k = (uint32_t)top_k;
-    // chunk rows so that the score slab stays <= ~2 GiB
-    size_t chunk = std::max<size_t>(SEG, std::min<size_t>(n ? n : 1, ((size_t)1 << 29) / std::max<size_t>(nq, 1)));
-    chunk = (chunk + SEG - 1) / SEG * SEG;
-    size_t n_chunks = n ? (n + chunk - 1) / chunk : 0;
-    size_t total_segs = 0;
-    for (size_t c = 0; c < n_chunks; c++) total_segs += (std::min(chunk, n - c * chunk) + SEG - 1) / SEG;
-    if (total_segs == 0) total_segs = 1;
-    float *S = nullptr;
-    uint64_t *candA = nullptr, *candB = nullptr, *best = nullptr;
-    size_t cand_len = std::max<size_t>(total_segs * k, k); // per query
-    HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * nq * std::max<size_t>(chunk, 1)));
-    HIP_CHECK_RET(hipMalloc((void **)&candA, sizeof(uint64_t) * nq * cand_len));
-    HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
-    HIP_CHECK_RET(hipMalloc((void **)&best, sizeof(uint64_t) * nq * k));
-    HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
-    HIP_CHECK_RET(hipMemsetAsync(best, 0xFF, sizeof(uint64_t) * nq * k, st));
-    size_t seg_off = 0;
-    int rc = LEANN_OK;
-    for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
-        size_t row0 = c * chunk, rows = std::min(chunk, n - row0), segs = 0;
-        rc = leann_internal_scan_chunk(d_rows + row0 * ld, rows, dims, ld, d_queries, nq, k, d_allow_mask, row0, S, candA, cand_len,
-                                       seg_off, st, &segs, nullptr, n_chunks > 1 ? best : nullptr);
-        seg_off += segs;
+    // Pass 1 (emission): a 64k-row slab + segment top-k fixes a first k-th best per query; the following launches (448k rows, then
+    // everything else) emit only the scores that reach it (CandEmit).  A candidate list that overflows (adversarial order) makes the
+    // call repeat on pass 2, the slab path: geometric chunks 128k, 512k, 2M, ... (slab <= 2 GiB) with threshold-pruned segment sorts.
+    for (int pass = (n > ((size_t)64 << 10) && !getenv("LEANN_DEBUG_NO_EMIT")) ? 1 : 2; pass <= 2; pass++) {
+        const bool emit = pass == 1;
+        std::vector<std::pair<size_t, size_t>> chunks;
+        {
+            const size_t cap_rows = std::max<size_t>(SEG, (((size_t)1 << 29) / std::max<size_t>(nq, 1)) / SEG * SEG);
+            size_t pos = 0, len = std::min(cap_rows, emit ? (size_t)64 << 10 : (size_t)128 << 10);
+            while (pos < n) {
+                const size_t rows = std::min(len, n - pos);
+                chunks.emplace_back(pos, rows);
+                pos += rows;
+                if (emit) len = chunks.size() == 1 ? (size_t)448 << 10 : n;
+                else len = std::min(cap_rows, len * 4);
+            }
+        }
+        const size_t n_chunks = chunks.size();
+        size_t slab_rows = SEG, total_segs = 0;
+        for (size_t c = 0; c < n_chunks; c++)
+            if (!emit || c == 0) { slab_rows = std::max(slab_rows, chunks[c].second); total_segs += (chunks[c].second + SEG - 1) / SEG; }
+        total_segs = std::max<size_t>(total_segs, 1);
+        const size_t cand_len = std::max<size_t>(total_segs * k, k); // per query
+        const size_t slots = (nq + 63) / 64 * 64;                     // score_mfma_kernel reads a threshold for every query of a tile
+        const uint32_t EMIT_CAP = 8192;
+        float *S = nullptr;
+        uint64_t *candA = nullptr, *candB = nullptr, *best = nullptr;
+        unsigned char *emb = nullptr; // [slots f32 thr | slots u32 cnt | u32 overflow | pad | slots x EMIT_CAP u64]
+        const size_t em_hdr = (slots * 8 + 4 + 255) / 256 * 256;
+        HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * nq * slab_rows));
+        HIP_CHECK_RET(hipMalloc((void **)&candA, sizeof(uint64_t) * nq * cand_len));
+        HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
+        HIP_CHECK_RET(hipMalloc((void **)&best, sizeof(uint64_t) * nq * k));
+        HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
+        HIP_CHECK_RET(hipMemsetAsync(best, 0xFF, sizeof(uint64_t) * nq * k, st));
+        CandEmit em{};
+        uint32_t *d_overflow = nullptr;
+        if (emit) {
+            HIP_CHECK_RET(hipMalloc((void **)&emb, em_hdr + sizeof(uint64_t) * slots * EMIT_CAP));
+            HIP_CHECK_RET(hipMemsetAsync(emb, 0, em_hdr, st));
+            em.thr = reinterpret_cast<const float *>(emb);
+            em.cnt = reinterpret_cast<uint32_t *>(emb + slots * 4);
+            d_overflow = reinterpret_cast<uint32_t *>(emb + slots * 8);
+            em.list = reinterpret_cast<uint64_t *>(emb + em_hdr);
+            em.cap = EMIT_CAP;
+            em.allow = d_allow_mask;
+        }
+        size_t seg_off = 0;
+        int rc = LEANN_OK;
+        for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
+            const size_t row0 = chunks[c].first, rows = chunks[c].second;
+            size_t segs = 0;
+            if (emit && c > 0) {
+                em.pos0 = row0;
+                dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
+                hipLaunchKernelGGL(score_mfma_kernel, g1, dim3(256), 0, st, d_rows + row0 * ld, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld,
+                                   d_queries, (uint32_t)nq, (uint32_t)dims, (uint64_t)0, (uint32_t)rows, S, em);
+            } else {
+                rc = leann_internal_scan_chunk(d_rows + row0 * ld, rows, dims, ld, d_queries, nq, k, d_allow_mask, row0, S, candA, cand_len,
+                                               seg_off, st, &segs, nullptr, (n_chunks > 1 || emit) ? best : nullptr);
+            }
+            if (rc == LEANN_OK && emit) rc = leann_internal_fold_candidates(em, k, (uint32_t)nq, (uint32_t)slots, best, d_overflow, st);
+            seg_off += segs;
+        }
+        if (rc == LEANN_OK) {
+            if (emit) rc = leann_internal_scan_finish(best, candB, k, 1, nq, k, key_offset, d_keys, d_scores, d_counts, st); // best = exact running top-k
+            else rc = leann_internal_scan_finish(candA, candB, cand_len, total_segs, nq, k, key_offset, d_keys, d_scores, d_counts, st);
+        }
+        // scratch is plain hipMalloc memory: wait for the stream before giving it back (this entry point
+        // is synchronous; the stream-ordered allocator proved unreliable on this stack)
+        (void)hipStreamSynchronize(st);
+        uint32_t ov = 0;
+        if (emit && rc == LEANN_OK && hipMemcpy(&ov, d_overflow, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = LEANN_ERR_DEVICE;
+        (void)hipFree(S);
+        (void)hipFree(candA);
+        (void)hipFree(candB);
+        (void)hipFree(best);
+        (void)hipFree(emb);
+        if (rc != LEANN_OK || !emit || ov == 0) return rc;
     }
-    if (rc == LEANN_OK)
-        rc = leann_internal_scan_finish(candA, candB, cand_len, total_segs, nq, k, key_offset, d_keys, d_scores, d_counts, st);
-    // scratch is plain hipMalloc memory: wait for the stream before giving it back (this entry point
-    // is synchronous; the stream-ordered allocator proved unreliable on this stack)
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(S);
-    (void)hipFree(candA);
-    (void)hipFree(candB);
-    (void)hipFree(best);
-    return rc;
+    return LEANN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

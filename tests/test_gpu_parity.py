@@ -202,6 +202,44 @@ def test_scan_topk_allow_mask_and_ties(la, po, gpu):
         assert (gk[i] == k1).all() and (gs[i] == s1).all()
 
 
+def test_scan_topk_candidate_emission_and_overflow(la, po, gpu, monkeypatch):
+    """> 64k rows: the launches after the first slab emit only scores that reach the running k-th best (no score slab, no segment
+    sorts).  Bit-exact against the oracle's k-ordered dot (duplicated rows: ties -> lower position), equal to the slab path, with an
+    allow mask, and with an adversarial order (scores rise with the position -> the lists overflow -> the call repeats on slabs)."""
+    n, d, nq, k = 200000, 128, 70, 10
+    base = synth(po, n // 2, d)
+    X = np.concatenate([base, base])
+    Q = synth(po, nq, d, stream=1)
+    mask = np.zeros((n + 7) // 8, np.uint8)
+    idx = np.arange(1, n, 3)
+    np.bitwise_or.at(mask, idx >> 3, (1 << (idx & 7)).astype(np.uint8))
+    dX, dQ, dM = la.DeviceArray.from_host(X), la.DeviceArray.from_host(Q), la.DeviceArray.from_host(mask)
+
+    def run(m=None, rows=dX):
+        dk, ds, dc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+        la._native.check(la.lib().leann_scan_topk_device(rows.ptr, n, d, d, dQ.ptr, nq, k, m.ptr if m is not None else None, 7, dk.ptr, ds.ptr,
+                                                         dc.ptr, None))
+        la.sync()
+        return dk.to_host(), ds.to_host(), dc.to_host()
+    gk, gs, gc = run()
+    mk, ms, mc = run(dM)
+    for i in (0, 31, 32, 69):
+        k1, s1 = po.scan_topk(X, Q[i], k, mode=1)
+        assert (gk[i] - 7 == k1).all() and (gs[i].view(np.uint32) == s1.view(np.uint32)).all()
+        k2, s2 = po.scan_topk(X, Q[i], k, mode=1, allow_mask=mask)
+        assert (mk[i] - 7 == k2).all() and (ms[i].view(np.uint32) == s2.view(np.uint32)).all()
+    # adversarial order: rows sorted by their score against query 0, ascending
+    order = np.argsort(X @ Q[0], kind="stable")
+    dXs = la.DeviceArray.from_host(X[order])
+    ak, as_, ac = run(rows=dXs)
+    monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")
+    sk, ss, sc = run()
+    assert (sk == gk).all() and (ss.view(np.uint32) == gs.view(np.uint32)).all()
+    bk, bs, bc = run(rows=dXs)
+    assert (ak == bk).all() and (as_.view(np.uint32) == bs.view(np.uint32)).all()
+    assert (ak[0] - 7 >= n - 40).all()  # query 0's winners sit at the very end
+
+
 def test_merge_topk_matches_oracle(la, po, gpu):
     rng = np.random.default_rng(5)
     S, nq, k_in, k_out = 8, 33, 10, 10
