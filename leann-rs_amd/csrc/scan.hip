@@ -36,50 +36,69 @@ __global__ void __launch_bounds__(256) score_mfma_kernel(const float *__restrict
                                                          uint32_t ldq, uint64_t row0, uint32_t n_rows,
                                                          float *__restrict__ S /* [nq x n_rows] */, CandEmit em = CandEmit{}) {
     constexpr int BR = 128, BQ = 64, BK = 32;
-    __shared__ float sX[BK][BR + 4]; // [k][row]
-    __shared__ float sQ[BK][BQ + 4]; // [k][query]
+    // LDS tiles [k][row] / [k][query], unpadded, XOR-swizzled columns: col ^ sw(k), sw(k) = 32 (k & 1) xor 8 ((k >> 2) & 7).
+    // Reads (k = 2s + lh, 32 consecutive columns per half wave) and the transposing writes (8 lanes = 8 k-groups of one row,
+    // 8 consecutive rows per instruction) are both bank-conflict free.
+    __shared__ float sX[BK][BR];
+    __shared__ float sQ[BK][BQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const uint32_t rbase = blockIdx.x * BR, qbase = blockIdx.y * BQ;
     f32x16 acc0, acc1; // query tile 0 / 1  x  row tile `wave`
 #pragma unroll
     for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    for (uint32_t k0 = 0; k0 < d; k0 += BK) {
-        { // stage rows: thread -> (row = tid/2, 16 consecutive k)
-            const int r = tid >> 1, kk = (tid & 1) * 16;
-            const uint32_t row = rbase + r;
-            const float *src = X + (size_t)(row0 + row) * ld + k0 + kk;
-            const bool rok = row < n_rows;
-#pragma unroll
-            for (int e4 = 0; e4 < 4; e4++) {
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                const uint32_t kq = k0 + kk + e4 * 4;
-                if (rok) {
-                    if (vec_ok && kq + 3 < ld) {
-                        float4 t = *reinterpret_cast<const float4 *>(src + e4 * 4);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) if (kq + e < ld) v[e] = src[e4 * 4 + e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; e++) sX[kk + e4 * 4 + e][r] = (kq + e < d) ? v[e] : 0.f;
+    const bool xvec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool qvec = ((ldq & 3) == 0) && ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
+    // staging map: thread -> (row / query = tid / 8 (+ 32 per pass), 4 consecutive k = 4 (tid % 8)): one wave instruction reads
+    // 8 rows x 128 B = whole lines (two threads per row touched 32 quarter lines per instruction and cost ~4x the address work)
+    const int sr = tid >> 3, kq = (tid & 7) * 4;
+    auto load4 = [&](const float *base, bool ok, bool vec, uint32_t k, uint32_t lim) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            if (vec && k + 3 < lim) v = *reinterpret_cast<const float4 *>(base + k);
+            else {
+                if (k + 0 < lim) v.x = base[k + 0];
+                if (k + 1 < lim) v.y = base[k + 1];
+                if (k + 2 < lim) v.z = base[k + 2];
+                if (k + 3 < lim) v.w = base[k + 3];
             }
-            // stage queries: thread -> (query = tid/4, 8 consecutive k)
-            const int qq = tid >> 2, kq0 = (tid & 3) * 8;
-            const uint32_t qi = qbase + qq;
-            const float *qs = Q + (size_t)qi * ldq + k0 + kq0;
-#pragma unroll
-            for (int e = 0; e < 8; e++) sQ[kq0 + e][qq] = (qi < nq && k0 + kq0 + e < d) ? qs[e] : 0.f;
         }
-        __syncthreads();
+        return v;
+    };
+    float4 xv[4], qv[2]; // the next k-tile travels in registers while the current one is multiplied
+    auto gload = [&](uint32_t k0) {
 #pragma unroll
-        for (int s = 0; s < BK / 2; s++) {
-            const float b = sX[2 * s + lh][wave * 32 + l31];
-            const float a0 = sQ[2 * s + lh][l31];
-            const float a1 = sQ[2 * s + lh][32 + l31];
+        for (int p = 0; p < 4; p++) {
+            const uint32_t row = rbase + sr + 32 * p;
+            xv[p] = load4(X + (size_t)(row0 + row) * ld, row < n_rows, xvec, k0 + kq, d);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const uint32_t qi = qbase + sr + 32 * p;
+            qv[p] = load4(Q + (size_t)qi * ldq, qi < nq, qvec, k0 + kq, d);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int k = kq + e, sw = (32 * (k & 1)) ^ (8 * ((k >> 2) & 7));
+#pragma unroll
+            for (int p = 0; p < 4; p++) sX[k][(sr + 32 * p) ^ sw] = e == 0 ? xv[p].x : e == 1 ? xv[p].y : e == 2 ? xv[p].z : xv[p].w;
+#pragma unroll
+            for (int p = 0; p < 2; p++) sQ[k][(sr + 32 * p) ^ sw] = e == 0 ? qv[p].x : e == 1 ? qv[p].y : e == 2 ? qv[p].z : qv[p].w;
+        }
+    };
+    gload(0);
+    for (uint32_t k0 = 0; k0 < d; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < d) gload(k0 + BK);
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 2; s2++) {
+            const int k = 2 * s2 + lh, sw = (32 * (k & 1)) ^ (8 * ((k >> 2) & 7));
+            const float b = sX[k][(wave * 32 + l31) ^ sw];
+            const float a0 = sQ[k][l31 ^ sw];
+            const float a1 = sQ[k][(32 + l31) ^ sw];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
         }
