@@ -712,7 +712,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     uint16_t *Gp = rw->sGp;
     uint64_t *candA = rw->sCandA, *candB = rw->sCandB, *best = rw->sBest;
     // chunks after the first emit their few survivors straight from the fused kernel (no score slab, no segment sort)
-    const uint32_t EMIT_CAP = 8192;
+    const uint32_t EMIT_CAP = std::max<uint32_t>(8192, 32 * k); // expected survivors per query ~ k * rows / rows_seen (x19 after 512k of 10M rows)
     const bool emit = emit_ok && use_fstat(r) && n_chunks > 1 && k <= 1024 && !getenv("LEANN_DEBUG_NO_EMIT");
     CandEmit em{};
     uint32_t *d_overflow = nullptr;

@@ -376,7 +376,7 @@ extern "C" int leann_scan_topk_device(const float *d_rows, size_t n, size_t dims
         total_segs = std::max<size_t>(total_segs, 1);
         const size_t cand_len = std::max<size_t>(total_segs * k, k); // per query
         const size_t slots = (nq + 63) / 64 * 64;                     // score_mfma_kernel reads a threshold for every query of a tile
-        const uint32_t EMIT_CAP = 8192;
+        const uint32_t EMIT_CAP = std::max<uint32_t>(8192, 32 * k); // expected survivors per query ~ k * rows / rows_seen (x19 after 512k of 10M rows)
         float *S = nullptr;
         uint64_t *candA = nullptr, *candB = nullptr, *best = nullptr;
         unsigned char *emb = nullptr; // [slots f32 thr | slots u32 cnt | u32 overflow | pad | slots x EMIT_CAP u64]

@@ -238,6 +238,13 @@ def test_scan_topk_candidate_emission_and_overflow(la, po, gpu, monkeypatch):
     bk, bs, bc = run(rows=dXs)
     assert (ak == bk).all() and (as_.view(np.uint32) == bs.view(np.uint32)).all()
     assert (ak[0] - 7 >= n - 40).all()  # query 0's winners sit at the very end
+    monkeypatch.delenv("LEANN_DEBUG_NO_EMIT")
+    # a deep list (k = 300): the candidate lists are sized with k
+    dk, ds, dc = la.DeviceArray((4, 300), np.uint64), la.DeviceArray((4, 300), np.float32), la.DeviceArray(4, np.uint32)
+    la._native.check(la.lib().leann_scan_topk_device(dX.ptr, n, d, d, dQ.ptr, 4, 300, None, 0, dk.ptr, ds.ptr, dc.ptr, None))
+    la.sync()
+    k1, s1 = po.scan_topk(X, Q[2], 300, mode=1)
+    assert (dk.to_host()[2] == k1).all() and (ds.to_host()[2].view(np.uint32) == s1.view(np.uint32)).all()
 
 
 def test_merge_topk_matches_oracle(la, po, gpu):
