@@ -195,6 +195,20 @@ def test_filtered_search_restatement(po):
         assert (sk[0] == pk[i]).all() and sc[0] == pc[i]
 
 
+def test_hand_built_graph_traced_visit_order(po):
+    """SURVEY 8c fixture (4): 64-node hand-built two-level graph over integer vectors; ids, distances, expansion and evaluation
+    counts traced by an independent pure-Python textbook HNSW (tests/golden/make_traced_graph.py) - both oracle formulations."""
+    from util import traced_graph
+    fx, X, levels, upper_off, adj0, adjU = traced_graph()
+    G = po.Graph.from_arrays(X, fx["M"], fx["M0"], fx["max_level"], fx["entry"], levels, upper_off, adj0, adjU)
+    for c in fx["cases"]:
+        q = np.array(c["query"], np.float32)
+        for algo in (0, 1):
+            keys, dists, st = G.search(q, c["k"], c["ef"], algo)
+            assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]]
+            assert int(st[0]) == c["n_evals"] and int(st[1]) == len(c["expanded_base"]) and int(st[2]) == len(c["expanded_upper"])
+
+
 def test_config0_plumbing_10k_x_128(po):
     """BASELINE configs[0]: 10k x 128 random f32 vectors, HNSW ef=64 (CPU, plumbing)."""
     X = synth(po, 10000, 128, r=0)

@@ -60,6 +60,21 @@ def test_hnsw_search_matches_oracle(la, po, gpu, n, d, M, ef):
     s.close()
 
 
+def test_hand_built_graph_traced_visit_order(la, gpu):
+    """the same fixture through the HIP kernel: ids, distances and the visit counters of the independent trace (no oracle involved)"""
+    from util import traced_graph
+    fx, X, levels, upper_off, adj0, adjU = traced_graph()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, fx["M"], fx["M0"], fx["max_level"], fx["entry"], levels, upper_off, adj0, adjU)
+    for c in fx["cases"]:
+        q = np.array(c["query"], np.float32)
+        s.stats(reset=True)
+        keys, dists = s.search(q, c["k"], c["ef"])
+        st = s.stats()
+        assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]]
+        assert st["n_dist_evals"] == c["n_evals"] and st["n_hops_base"] == len(c["expanded_base"]) and st["n_hops_upper"] == len(c["expanded_upper"])
+    s.close()
+
+
 def test_vamana_search_matches_oracle(la, po, gpu):
     n, d, R = 2500, 128, 24
     X = synth(po, n, d)

@@ -15,3 +15,15 @@ def recall_at_k(found, truth):
     for f, t in zip(found, truth):
         hits += len(set(int(x) for x in f[:k]) & set(int(x) for x in t))
     return hits / (len(truth) * k)
+
+
+def traced_graph():
+    """tests/golden/traced_graph_64.json as arrays: the hand-built 64-node graph + the independently traced expectations"""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traced_graph_64.json")))
+    X = np.array(fx["vectors"], np.float32)
+    levels = np.array(fx["levels"], np.uint8)
+    upper_off = np.concatenate([[0], np.cumsum(levels)[:-1]]).astype(np.uint32)
+    adj0 = np.array(fx["adj0"], np.uint32)
+    adjU = np.array(fx["adjU"], np.uint32)
+    return fx, X, levels, upper_off, adj0, adjU
