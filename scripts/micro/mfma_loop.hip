@@ -59,6 +59,9 @@ __global__ void __launch_bounds__(256) k(unsigned long long *out, const bf16x8 *
                 asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %5, %6 offset:%7\n\t" MM "%0, %2, %4, %0\n\t" MM "%1, %3, %4, %1"
                              : "+v"(c0), "+v"(c1) : "a"(a0), "a"(a1), "v"(b0), "v"(b1), "v"(addr), "i"(u * 4096) : "memory");
             }
+            if (MODE == 11) // the score-tile form: A = ring fragment (VGPR), B = resident fragment (AGPR)
+                asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %5, %6 offset:%7\n\t" MM "%0, %4, %2, %0\n\t" MM "%1, %4, %3, %1"
+                             : "+v"(c0), "+v"(c1) : "a"(a0), "a"(a1), "v"(b0), "v"(b1), "v"(addr), "i"(u * 4096) : "memory");
             if (MODE == 5) { asm volatile("ds_read_b128 %5, %6 offset:%7\n\t" MM "%0, %2, %4, %0\n\t" MM "%1, %3, %4, %1\n\ts_waitcnt lgkmcnt(0)"
                              : "+v"(c0), "+v"(c1) : "a"(a0), "a"(a1), "v"(b0), "v"(b1), "v"(addr), "i"(u * 4096) : "memory"); }
         }
@@ -73,11 +76,11 @@ __global__ void __launch_bounds__(256) k(unsigned long long *out, const bf16x8 *
 int main() {
     unsigned long long *out; bf16x8 *in; float *sink;
     hipMalloc(&out, 8 * 1024); hipMalloc(&in, 16 * 1024); hipMalloc(&sink, 4 * 256 * 1024); hipMemset(in, 0x3c, 16 * 1024);
-    const char *names[] = {"2 MFMA", "wait(3) + ds_read_b128 + 2 MFMA", "... + 2 v_fma_f32 on the accumulators", "... + 1 v_pk_fma_f32 (independent)", "wait(3) + 2 MFMA (no read)", "ds_read + 2 MFMA + wait(0)", "in-asm: 1 v_fma behind each MFMA", "in-asm: 2 v_fma behind each MFMA", "compiler-placed 1 scalar v_fma per iteration", "1 LDS-DMA piece per 4 iterations, in-stream", "4 LDS-DMA pieces back to back per 16 iterations"};
-    for (int grid : {256}) for (int m = 0; m < 11; m++) {
+    const char *names[] = {"2 MFMA", "wait(3) + ds_read_b128 + 2 MFMA", "... + 2 v_fma_f32 on the accumulators", "... + 1 v_pk_fma_f32 (independent)", "wait(3) + 2 MFMA (no read)", "ds_read + 2 MFMA + wait(0)", "in-asm: 1 v_fma behind each MFMA", "in-asm: 2 v_fma behind each MFMA", "compiler-placed 1 scalar v_fma per iteration", "1 LDS-DMA piece per 4 iterations, in-stream", "4 LDS-DMA pieces back to back per 16 iterations", "wait + read + 2 MFMA, A = VGPR fragment, B = AGPR"};
+    for (int grid : {256}) for (int m = 0; m < 12; m++) {
         for (int rep = 0; rep < 2; rep++) {
 #define L(M) if (m == M) { hipFuncSetAttribute((const void *)k<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); hipLaunchKernelGGL(k<M>, dim3(grid), dim3(256), 65536, 0, out, in, sink); }
-            L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10)
+            L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11)
             hipDeviceSynchronize();
         }
         unsigned long long h[256]; hipMemcpy(h, out, 8 * grid, hipMemcpyDeviceToHost);
