@@ -118,26 +118,31 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
                  : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [q0] "+v"(Q0_), [q1] "+v"(Q1_)                                \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [cnt] "i"(CNT_), [p0] "v"(P0_), [p1] "v"(P1_), [vo] "v"(VO_), [sb] "s"(SB_),  \
                    [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
-// G: acc += A(query-projection frag, VGPR) x B(feature frag, AGPR)
-#define FSTAT_G_RD_D(C0_, C1_, A0_, A1_, G_, NG_, ADDR_, OFF_, CNT_, VO_, SB_, LD_, DOFF_)                                  \
-    asm volatile("s_waitcnt lgkmcnt(%[cnt])\n\tds_read_b128 %[ng], %[addr] offset:%[off]\n\t" FSTAT_MM "%[x0], %[gg], %[f0], %[x0]\n\t" \
-                 FSTAT_DMA FSTAT_MM "%[x1], %[gg], %[f1], %[x1]"                                                             \
-                 : [x0] "+v"(C0_), [x1] "+v"(C1_), [gg] "+v"(G_), [ng] "=&v"(NG_)                                              \
-                 : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_), [vo] "v"(VO_), [sb] "s"(SB_), \
-                   [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
-#define FSTAT_G_NR_D(C0_, C1_, A0_, A1_, G_, CNT_, VO_, SB_, LD_, DOFF_)                                                    \
-    asm volatile("s_waitcnt lgkmcnt(%[cnt])\n\t" FSTAT_MM "%[x0], %[gg], %[f0], %[x0]\n\t" FSTAT_DMA FSTAT_MM "%[x1], %[gg], %[f1], %[x1]" \
-                 : [x0] "+v"(C0_), [x1] "+v"(C1_), [gg] "+v"(G_)                                                               \
-                 : [f0] "a"(A0_), [f1] "a"(A1_), [cnt] "i"(CNT_), [vo] "v"(VO_), [sb] "s"(SB_), [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
-#define FSTAT_G_RD(c0, c1, a0, a1, g, ng, addr, off, cnt)                                                                     \
-    asm volatile("s_waitcnt lgkmcnt(%8)\n\tds_read_b128 %3, %6 offset:%7\n\t" FSTAT_MM "%0, %2, %4, %0\n\t" FSTAT_MM "%1, %2, %5, %1" \
-                 : "+v"(c0), "+v"(c1), "+v"(g), "=&v"(ng) : "a"(a0), "a"(a1), "v"(addr), "i"(off), "i"(cnt) : "memory")
-#define FSTAT_G_RDZ(c0, c1, a0, a1, g, ng, addr, off, cnt)                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(%8)\n\tds_read_b128 %3, %6 offset:%7\n\t" FSTAT_MM "%0, %2, %4, 0\n\t" FSTAT_MM "%1, %2, %5, 0" \
-                 : "=&v"(c0), "=&v"(c1), "+v"(g), "=&v"(ng) : "a"(a0), "a"(a1), "v"(addr), "i"(off), "i"(cnt) : "memory")
-#define FSTAT_G_NR(c0, c1, a0, a1, g, cnt)                                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(%5)\n\t" FSTAT_MM "%0, %2, %3, %0\n\t" FSTAT_MM "%1, %2, %4, %1"                         \
-                 : "+v"(c0), "+v"(c1), "+v"(g) : "a"(a0), "a"(a1), "i"(cnt) : "memory")
+// One statement per k-step of the score-tile loop: the three pieces (hi, lo, lo2) of the k-step, their ring reads, six MFMAs and one
+// LDS-DMA piece.  S0/S1/S2 = ring slots of this k-step's fragments (S0 and S1 are re-filled in place with fragments f + 5, f + 6 once
+// their MFMAs have issued), S4 = the free slot taking fragment f + 4.  Z: the accumulators start from 0; T1 / T0: the last two
+// k-steps (two / no reads left).
+#define FSTAT_GK_MM(slot, c) FSTAT_MM "%[x0], %[" #slot "], %[f0], " c "\n\t"
+#define FSTAT_GK_OPS_OUT(C0_, C1_, S0_, S1_, S2_) [x0] "+v"(C0_), [x1] "+v"(C1_), [s0] "+v"(S0_), [s1] "+v"(S1_), [s2] "+v"(S2_)
+#define FSTAT_GK_OPS_IN(A0_, A1_, ADDR_, VO_, SB_, LD_, DOFF_) \
+    [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [vo] "v"(VO_), [sb] "s"(SB_), [ld] "s"(LD_), [doff] "i"(DOFF_)
+#define FSTAT_GK_BODY(Z0, Z1, RD0, RD1, RD2, W0, W1, W2)                                                                       \
+    "s_waitcnt lgkmcnt(" W0 ")\n\t" RD0 FSTAT_MM "%[x0], %[s0], %[f0], " Z0 "\n\t" FSTAT_MM "%[x1], %[s0], %[f1], " Z1 "\n\t"   \
+    "s_waitcnt lgkmcnt(" W1 ")\n\t" RD1 FSTAT_MM "%[x0], %[s1], %[f0], %[x0]\n\t" FSTAT_DMA FSTAT_MM "%[x1], %[s1], %[f1], %[x1]\n\t" \
+    "s_waitcnt lgkmcnt(" W2 ")\n\t" RD2 FSTAT_MM "%[x0], %[s2], %[f0], %[x0]\n\t" FSTAT_MM "%[x1], %[s2], %[f1], %[x1]"
+#define FSTAT_GK_RD(dst, off) "ds_read_b128 %[" #dst "], %[addr] offset:%[" #off "]\n\t"
+#define FSTAT_GK_FULL(Z0, Z1, C0_, C1_, S0_, S1_, S2_, S4_, A0_, A1_, ADDR_, O4_, O5_, O6_, VO_, SB_, LD_, DOFF_)              \
+    asm volatile(FSTAT_GK_BODY(Z0, Z1, FSTAT_GK_RD(s4, o4), FSTAT_GK_RD(s0, o5), FSTAT_GK_RD(s1, o6), "3", "3", "3")           \
+                 : FSTAT_GK_OPS_OUT(C0_, C1_, S0_, S1_, S2_), [s4] "=&v"(S4_)                                                  \
+                 : FSTAT_GK_OPS_IN(A0_, A1_, ADDR_, VO_, SB_, LD_, DOFF_), [o4] "i"(O4_), [o5] "i"(O5_), [o6] "i"(O6_) : "memory")
+#define FSTAT_GK_T1(C0_, C1_, S0_, S1_, S2_, S4_, A0_, A1_, ADDR_, O4_, O5_, VO_, SB_, LD_, DOFF_)                              \
+    asm volatile(FSTAT_GK_BODY("%[x0]", "%[x1]", FSTAT_GK_RD(s4, o4), FSTAT_GK_RD(s0, o5), "", "3", "3", "3")                   \
+                 : FSTAT_GK_OPS_OUT(C0_, C1_, S0_, S1_, S2_), [s4] "=&v"(S4_)                                                  \
+                 : FSTAT_GK_OPS_IN(A0_, A1_, ADDR_, VO_, SB_, LD_, DOFF_), [o4] "i"(O4_), [o5] "i"(O5_) : "memory")
+#define FSTAT_GK_T0(C0_, C1_, S0_, S1_, S2_, A0_, A1_, ADDR_, VO_, SB_, LD_, DOFF_)                                            \
+    asm volatile(FSTAT_GK_BODY("%[x0]", "%[x1]", "", "", "", "2", "1", "0")                                                   \
+                 : FSTAT_GK_OPS_OUT(C0_, C1_, S0_, S1_, S2_)                                                                   \
+                 : FSTAT_GK_OPS_IN(A0_, A1_, ADDR_, VO_, SB_, LD_, DOFF_) : "memory")
 // Candidate emission (chunks after the first): CandEmit, internal.h.
 #define FSTAT_MAX_QUERIES 256 // queries per launch: the encode GEMM is shared, each 32-query tile adds one G sub-slice per unit
 #define LEANN_FSTAT_RB 2 // 32-passage blocks per wave (the per-k-step asm statements are written for two)
@@ -306,7 +311,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 // 4 column tiles x KS k-steps, flat: fragment f+RING is requested while fragment f is multiplied.  The reads
                 // are asm statements (the compiler's scheduler otherwise sinks every read to just before its use, which with
                 // one wave per SIMD exposes the LDS latency 64 times per sub-slice); their lgkmcnt is counted by hand.
-                static_assert(RB == 2 && RING == 4, "the per-k-step asm statements are written for two passage blocks and a 4-deep ring");
+                static_assert(RB == 2 && RING == 4 && KS >= 3, "the per-k-step asm statements are written for two passage blocks and a 4-deep ring");
                 bf16x8 bq[RING + 1];
                 static_for<RING>([&bq, &waddr](auto fc) __attribute__((always_inline)) {
                     constexpr int f = decltype(fc)::value;
@@ -404,24 +409,25 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                         constexpr int f = decltype(fc)::value;
                         FSTAT_DS_READ(gq[f], waddr, (f / 3) * KSB + (f % 3) * 1024);
                     });
-                    static_for<3 * KS>([&sc, &gq, &a, &waddr, &nprow0, &load_features, &dsb, &dld, &goff](auto fc) __attribute__((always_inline)) {
-                        // k-step major (pieces hi, lo, lo2 innermost): a feature fragment is dead after its k-step, so the next
-                        // unit's feature loads spread over the whole visit instead of bunching in the last third
-                        constexpr int f = decltype(fc)::value, piece = f % 3, ks = f / 3, NF = 3 * KS;
-                        bf16x8 &g = gq[f % (RING + 1)];
-                        bf16x8 &ng = gq[(f + RING) % (RING + 1)];
-                        constexpr int noff = ((f + RING) / 3) * KSB + ((f + RING) % 3) * 1024;
-                        constexpr bool dma = f % 3 == 1;                       // piece f / 3 of the next sub-slice
-                        constexpr int dt = (f / 3) >> 2, doff = ((f / 3) & 3) * 1024;
-                        if constexpr (f + RING < NF) { // C[i = query][j = passage]
-                            if constexpr (f == 0) FSTAT_G_RDZ(sc[0], sc[1], a[0][ks], a[1][ks], g, ng, waddr, noff, RING - 1);
-                            else if constexpr (dma) FSTAT_G_RD_D(sc[0], sc[1], a[0][ks], a[1][ks], g, ng, waddr, noff, RING - 1, goff, dsb[dt], dld[dt], doff);
-                            else FSTAT_G_RD(sc[0], sc[1], a[0][ks], a[1][ks], g, ng, waddr, noff, RING - 1);
+                    // k-step major (pieces hi, lo, lo2 innermost): a feature fragment is dead after its k-step, so the next unit's
+                    // feature loads spread over the whole visit instead of bunching in the last third
+                    static_for<KS>([&sc, &gq, &a, &waddr, &nprow0, &load_features, &dsb, &dld, &goff](auto kc) __attribute__((always_inline)) {
+                        constexpr int ks = decltype(kc)::value, f = 3 * ks, NF = 3 * KS;
+                        bf16x8 &s0 = gq[f % 5], &s1 = gq[(f + 1) % 5], &s2 = gq[(f + 2) % 5], &s4 = gq[(f + 4) % 5];
+                        constexpr int o4 = ((f + 4) / 3) * KSB + ((f + 4) % 3) * 1024, o5 = ((f + 5) / 3) * KSB + ((f + 5) % 3) * 1024,
+                                      o6 = ((f + 6) / 3) * KSB + ((f + 6) % 3) * 1024;
+                        constexpr int dt = ks >> 2, doff = (ks & 3) * 1024; // LDS-DMA piece ks of the next sub-slice
+                        if constexpr (f + 6 < NF) { // C[i = query][j = passage]
+                            if constexpr (ks == 0)
+                                FSTAT_GK_FULL("0", "0", sc[0], sc[1], s0, s1, s2, s4, a[0][ks], a[1][ks], waddr, o4, o5, o6, goff, dsb[dt], dld[dt], doff);
+                            else
+                                FSTAT_GK_FULL("%[x0]", "%[x1]", sc[0], sc[1], s0, s1, s2, s4, a[0][ks], a[1][ks], waddr, o4, o5, o6, goff, dsb[dt], dld[dt], doff);
+                        } else if constexpr (f + 5 < NF) {
+                            FSTAT_GK_T1(sc[0], sc[1], s0, s1, s2, s4, a[0][ks], a[1][ks], waddr, o4, o5, goff, dsb[dt], dld[dt], doff);
                         } else {
-                            if constexpr (dma) FSTAT_G_NR_D(sc[0], sc[1], a[0][ks], a[1][ks], g, NF - f - 1, goff, dsb[dt], dld[dt], doff);
-                            else FSTAT_G_NR(sc[0], sc[1], a[0][ks], a[1][ks], g, NF - f - 1);
+                            FSTAT_GK_T0(sc[0], sc[1], s0, s1, s2, a[0][ks], a[1][ks], waddr, goff, dsb[dt], dld[dt], doff);
                         }
-                        if constexpr (PF && piece == 2) load_features(a, nprow0, ks);
+                        if constexpr (PF) load_features(a, nprow0, ks);
                     });
                 };
                 if (qt == nqt - 1) g_loop(std::true_type{});
