@@ -244,6 +244,26 @@ def bench_scan(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log):
                         "frac": nbytes / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "score_mfma_kernel (+ topk_scores_kernel)",
                         "algorithmic_bytes_per_step": nbytes, "f32_mfma_tflops": flops / step_s / 1e12,
                         "f32_mfma_frac": flops / step_s / 1e12 / F32_MFMA_PEAK_TFLOPS}}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:  # CPU baseline: the oracle's literal dot + stable sort + take on the host cores
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import pyoracle as po
+            from concurrent.futures import ThreadPoolExecutor
+            cores = host_cores()
+            ns = min(rows, 10_000_000)  # ~5 s of CPU work per thread at 10M x 768
+            Xh = X[:ns, :d].contiguous().cpu().numpy()
+            Qh = Q[:cores, :d].contiguous().cpu().numpy()
+            with ThreadPoolExecutor(cores) as ex:  # one query per host thread (ctypes releases the GIL)
+                list(ex.map(lambda i: po.scan_topk(Xh[:65536], Qh[i], k, mode=0), range(cores)))
+                t0 = time.perf_counter()
+                list(ex.map(lambda i: po.scan_topk(Xh, Qh[i], k, mode=0), range(cores)))
+                cpu_s = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": cores / (cpu_s * rows / ns), "unit": "queries/s", "cores": cores, "kind": "port",
+                                   "sample": f"{cores} queries (one per host thread) over {ns} of the {rows} rows (oracle/oracle.c:orc_scan_topk, the "
+                                             f"sequential dot + stable sort + take of recompute.rs:96-109), {cpu_s:.2f} s; value = extrapolated to all rows"}
+            log(f"cpu baseline: {out['cpu_baseline']['value']:.2f} q/s")
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

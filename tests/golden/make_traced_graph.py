@@ -88,10 +88,41 @@ def knn(q, k, ef):
             "n_evals": 1 + len(t1["evaluated"]) + len(t0["evaluated"])}
 
 
+def greedy_search(q, start, L):
+    """DiskANN / Vamana Alg. 1 (GreedySearch) on the level-0 graph: one list of at most L entries sorted by (dist, id); repeatedly
+    expand the closest entry that has not been expanded yet."""
+    lst = [(dist(q, start), start)]
+    seen, done, expanded, n_evals = {start}, set(), [], 1
+    while True:
+        pending = [x for x in lst if x[1] not in done]
+        if not pending:
+            break
+        d, c = min(pending)
+        done.add(c)
+        expanded.append(c)
+        for e in adj0[c]:
+            if e in seen:
+                continue
+            seen.add(e)
+            n_evals += 1
+            lst.append((dist(q, e), e))
+        lst = sorted(lst)[:L]
+    return lst, expanded, n_evals
+
+
+def vamana(q, k, L):
+    L = max(L, k)
+    lst, expanded, n_evals = greedy_search(q, 0, L)
+    return {"k": k, "L": L, "query": q, "ids": [e for _, e in lst[:k]], "dists": [d for d, _ in lst[:k]], "expanded": expanded,
+            "n_evals": n_evals}
+
+
 queries = [vec(63), vec(27), [1 if j in (2, 13) else 0 for j in range(D)], [2, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 3, 0, 0, 0, 0]]
 cases = [knn(q, k, ef) for q in queries for k, ef in ((5, 8), (3, 3), (10, 16))]
 fix = {"n": N, "d": D, "M": M, "M0": M0, "entry": 0, "max_level": 1, "vectors": X, "levels": levels,
        "adj0": [nb + [EMPTY] * (M0 - len(nb)) for nb in adj0],
-       "upper_nodes": upper, "adjU": [adjU[i] + [EMPTY] * (M - len(adjU[i])) for i in upper], "cases": cases}
+       "upper_nodes": upper, "adjU": [adjU[i] + [EMPTY] * (M - len(adjU[i])) for i in upper], "cases": cases,
+       # the level-0 graph alone, searched as a Vamana index from node 0 (DiskAnnSearcher: beam = max(complexity, k), diskann.rs:54)
+       "vamana_cases": [vamana(q, k, L) for q in queries for k, L in ((5, 8), (3, 2), (10, 16))]}
 json.dump(fix, open(os.path.join(HERE, "traced_graph_64.json"), "w"))
 print(len(cases), "cases;", cases[0]["expanded_base"][:10], cases[0]["ids"])

@@ -207,6 +207,15 @@ def test_hand_built_graph_traced_visit_order(po):
             keys, dists, st = G.search(q, c["k"], c["ef"], algo)
             assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]]
             assert int(st[0]) == c["n_evals"] and int(st[1]) == len(c["expanded_base"]) and int(st[2]) == len(c["expanded_upper"])
+    # the level-0 graph alone as a Vamana index: GreedySearch (DiskANN Alg. 1) traced independently
+    V = po.Graph.from_arrays(X, fx["M0"], fx["M0"], 0, 0, np.zeros(fx["n"], np.uint8), np.zeros(fx["n"], np.uint32), adj0,
+                             np.zeros((0, fx["M0"]), np.uint32))
+    for c in fx["vamana_cases"]:
+        q = np.array(c["query"], np.float32)
+        for algo in (0, 1):
+            keys, dists, st = V.search(q, c["k"], c["L"], algo)
+            assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]]
+            assert int(st[0]) == c["n_evals"] and int(st[1]) == len(c["expanded"])
 
 
 def test_config0_plumbing_10k_x_128(po):

@@ -73,6 +73,15 @@ def test_hand_built_graph_traced_visit_order(la, gpu):
         assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]]
         assert st["n_dist_evals"] == c["n_evals"] and st["n_hops_base"] == len(c["expanded_base"]) and st["n_hops_upper"] == len(c["expanded_upper"])
     s.close()
+    v = la.BackendSearcher.from_arrays(la.BackendType.DiskAnn, X, fx["M0"], fx["M0"], 0, 0, np.zeros(fx["n"], np.uint8),
+                                       np.zeros(fx["n"], np.uint32), adj0, np.zeros((0, fx["M0"]), np.uint32))
+    for c in fx["vamana_cases"]:  # GreedySearch (DiskANN Alg. 1) traced independently
+        v.stats(reset=True)
+        keys, dists = v.search(np.array(c["query"], np.float32), c["k"], c["L"])
+        st = v.stats()
+        assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]]
+        assert st["n_dist_evals"] == c["n_evals"] and st["n_hops_base"] == len(c["expanded"])
+    v.close()
 
 
 def test_vamana_search_matches_oracle(la, po, gpu):
