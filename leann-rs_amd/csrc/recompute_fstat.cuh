@@ -135,6 +135,10 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
     asm volatile(FSTAT_GK_BODY(Z0, Z1, FSTAT_GK_RD(s4, o4), FSTAT_GK_RD(s0, o5), FSTAT_GK_RD(s1, o6), "3", "3", "3")           \
                  : FSTAT_GK_OPS_OUT(C0_, C1_, S0_, S1_, S2_), [s4] "=&v"(S4_)                                                  \
                  : FSTAT_GK_OPS_IN(A0_, A1_, ADDR_, VO_, SB_, LD_, DOFF_), [o4] "i"(O4_), [o5] "i"(O5_), [o6] "i"(O6_) : "memory")
+#define FSTAT_GK_FULL_Z(C0_, C1_, S0_, S1_, S2_, S4_, A0_, A1_, ADDR_, O4_, O5_, O6_, VO_, SB_, LD_, DOFF_) /* accumulators start from 0 */ \
+    asm volatile(FSTAT_GK_BODY("0", "0", FSTAT_GK_RD(s4, o4), FSTAT_GK_RD(s0, o5), FSTAT_GK_RD(s1, o6), "3", "3", "3")           \
+                 : [x0] "=&v"(C0_), [x1] "=&v"(C1_), [s0] "+v"(S0_), [s1] "+v"(S1_), [s2] "+v"(S2_), [s4] "=&v"(S4_)           \
+                 : FSTAT_GK_OPS_IN(A0_, A1_, ADDR_, VO_, SB_, LD_, DOFF_), [o4] "i"(O4_), [o5] "i"(O5_), [o6] "i"(O6_) : "memory")
 #define FSTAT_GK_T1(C0_, C1_, S0_, S1_, S2_, S4_, A0_, A1_, ADDR_, O4_, O5_, VO_, SB_, LD_, DOFF_)                              \
     asm volatile(FSTAT_GK_BODY("%[x0]", "%[x1]", FSTAT_GK_RD(s4, o4), FSTAT_GK_RD(s0, o5), "", "3", "3", "3")                   \
                  : FSTAT_GK_OPS_OUT(C0_, C1_, S0_, S1_, S2_), [s4] "=&v"(S4_)                                                  \
@@ -419,7 +423,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                         constexpr int dt = ks >> 2, doff = (ks & 3) * 1024; // LDS-DMA piece ks of the next sub-slice
                         if constexpr (f + 6 < NF) { // C[i = query][j = passage]
                             if constexpr (ks == 0)
-                                FSTAT_GK_FULL("0", "0", sc[0], sc[1], s0, s1, s2, s4, a[0][ks], a[1][ks], waddr, o4, o5, o6, goff, dsb[dt], dld[dt], doff);
+                                FSTAT_GK_FULL_Z(sc[0], sc[1], s0, s1, s2, s4, a[0][ks], a[1][ks], waddr, o4, o5, o6, goff, dsb[dt], dld[dt], doff);
                             else
                                 FSTAT_GK_FULL("%[x0]", "%[x1]", sc[0], sc[1], s0, s1, s2, s4, a[0][ks], a[1][ks], waddr, o4, o5, o6, goff, dsb[dt], dld[dt], doff);
                         } else if constexpr (f + 5 < NF) {

@@ -16,6 +16,42 @@ def vregs(tok):
     return out
 
 
+def scan_mfma_hazards(asm_text, min_mfmas=4):
+    """hipcc does not know the asm statements are MFMAs, so it inserts no wait states between an MFMA and a VALU instruction that
+    reads its accumulator, and the hardware does not interlock.  Every v_* instruction (compiler-generated or an
+    in-asm filler) that reads a VGPR accumulator must come >= min_mfmas MFMAs (>= 128 cycles) or a pair of `s_nop 7` pads after
+    the last MFMA that wrote it.  Straight-line approximation: ages are tracked in file order within a kernel."""
+    bad = []
+    for m in re.finditer(r'^(_Z\d+fused_fstat_kernel\w*):', asm_text, re.M):
+        body = asm_text[m.end():asm_text.index('s_endpgm', m.end())].split('\n')
+        age = {}  # vgpr -> MFMAs issued since an MFMA last wrote it
+        for ln, l in enumerate(body):
+            t = l.strip()
+            if not t or t[0] in ';.' or t.endswith(':') or 'ASM' in t:
+                continue
+            if t.startswith('v_mfma'):
+                ops = t.split(None, 1)[1].split(',')
+                dst = vregs(ops[0])
+                for r in age:
+                    age[r] += 1
+                for r in dst:
+                    age[r] = 0
+                continue
+            if t.startswith('s_nop 7'):
+                for r in age:
+                    age[r] += 2  # 8 wait states; two of them in a row clear the hazard
+                continue
+            if t.startswith('v_') and ',' in t:  # sources only: a pure overwrite of a stale accumulator register is harmless
+                regs = vregs(','.join(t.split(None, 1)[1].split(',')[1:]))
+                hot = [r for r in regs if age.get(r, 99) < min_mfmas]
+                if hot:
+                    bad.append((m.group(1), ln, t, hot[:4]))
+            if t.startswith(('ds_read', 'global_load', 'v_')):  # an overwrite by something else ends the tracking of that register
+                for r in vregs(t.split(None, 1)[1].split(',')[0]):
+                    age.pop(r, None)
+    return bad
+
+
 def scan(asm_text):
     bad, kernels = [], 0
     for m in re.finditer(r'^(_Z\d+fused_fstat_kernel\w*):', asm_text, re.M):
@@ -51,11 +87,14 @@ def main():
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", os.path.join(ROOT, "leann-rs_amd/csrc/recompute.hip"), "-o", out]
         subprocess.run(cmd, check=True, capture_output=True)
-        kernels, bad = scan(open(out).read())
+        text = open(out).read()
+        kernels, bad = scan(text)
+        haz = scan_mfma_hazards(text)
     print(f"{kernels} fused_fstat_kernel instantiations scanned, {len(bad)} early reads of in-flight asm ds_read destinations")
-    for b in bad[:10]:
+    print(f"{len(haz)} vector instructions reading an accumulator within 4 MFMAs of its last MFMA write")
+    for b in bad[:10] + haz[:10]:
         print("  ", b)
-    return 1 if bad or kernels == 0 else 0
+    return 1 if bad or haz or kernels == 0 else 0
 
 
 if __name__ == "__main__":
