@@ -234,12 +234,6 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
 
     if (blockIdx.x >= n_units) return;
     if (em.thr) sThr[tid] = em.thr[tid]; // 256 threads, FSTAT_MAX_QUERIES = 256 slots; // visible to every wave long before its first use (a barrier per sub-slice)
-    // Every workgroup does the same work per unit, so all 256 would fetch their next features in the same few microseconds
-    // and queue on HBM (~14 000 cycles per unit).  On long launches the workgroups of an XCD start 1/8 of a unit apart.
-    if (n_units >= 8ull * gridDim.x) {
-        const int phase = (blockIdx.x >> 3) & 7;
-        for (int i = 0; i < phase; i++) __builtin_amdgcn_s_sleep(127); // ~8 000 cycles each
-    }
     bf16x8 a[RB][KS];
     {
         const uint64_t prow0 = (uint64_t)blockIdx.x * UNIT + (uint64_t)wave * (RB * 32);
