@@ -12,7 +12,7 @@
 //
 // Search (leann_recompute_search_batch[_device]), per tile of <= 64 queries: G = W Q^T once (project_queries_kernel), then
 //   * common shape (h = 256, dims % 128 == 0, one token row per passage): fused_fstat_kernel (recompute_fstat.cuh) — encode GEMM,
-//     row norms, feature-space scoring and candidate emission in one persistent kernel; first 64k rows through a score slab +
+//     row norms, feature-space scoring and candidate emission in one persistent kernel; first 16k rows through a score slab +
 //     segment top-k (scan.hip) to establish the running k-th best, the rest emits survivors only (fold_candidates_kernel);
 //   * other shapes: encode_kernel<CT, FUSED, POOL> below (128 passages x all columns per workgroup, both operands through LDS,
 //     masked mean pooling over L token rows in the epilogue) + score slab + segment top-k per chunk.
@@ -665,15 +665,15 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     // which topk_scores_kernel skips almost every segment unsorted
     std::vector<std::pair<size_t, size_t>> chunks; // (row0, rows)
     {
-        // with candidate emission only the first chunk needs a score slab: 64k rows fix a first k-th-best bound, the next 448k
-        // tighten it (~k * 448k / 64k survivors per query), everything else goes through ONE persistent launch
+        // with candidate emission only the first chunk needs a score slab: 16k rows fix a first k-th-best bound, the next 496k
+        // tighten it (~k * 496k / 16k survivors per query), everything else goes through ONE persistent launch
         const bool emit_schedule = emit_ok && use_fstat(r) && !getenv("LEANN_DEBUG_NO_EMIT");
-        size_t pos = 0, len = emit_schedule ? (size_t)64 << 10 : (size_t)128 << 10;
+        size_t pos = 0, len = emit_schedule ? (size_t)16 << 10 : (size_t)128 << 10;
         while (pos < r->n) {
             size_t rows = std::min(len, r->n - pos);
             chunks.emplace_back(pos, rows);
             pos += rows;
-            if (emit_schedule) len = chunks.size() == 1 ? (size_t)448 << 10 : r->n;
+            if (emit_schedule) len = chunks.size() == 1 ? (size_t)496 << 10 : r->n;
             else len = std::min<size_t>(len * 4, (size_t)4 << 20);
         }
     }
