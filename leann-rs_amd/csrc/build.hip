@@ -3,8 +3,9 @@
 // Replaces the arithmetic behind
 //     hnsw::build_index / add_to_index   src/backend/hnsw.rs:96-191   (usearch add loop, out of tree)
 //     diskann::build_index               src/backend/diskann.rs:70-105 (diskann-rs Vamana, out of tree)
-// with batched insertion: points enter in position order (hnsw.rs:128-130) in batches no larger than
-// the graph built so far; every point of a batch
+// with batched insertion: points enter in a fixed pseudo-random permutation of their positions (see
+// insertion_order below; hnsw.rs:128-130 adds row by row) in batches no larger than the graph built so
+// far; every point of a batch
 //   1. searches the current graph with the SAME traversal kernel as queries (search.cuh; ef =
 //      `complexity`, one launch per level that has new members),
 //   2. keeps at most M neighbours by the select-neighbours heuristic (HNSW Alg. 4; Vamana
@@ -321,13 +322,6 @@ __global__ void fill_u32_kernel(uint32_t *p, size_t n, uint32_t v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-__global__ void iota_skip_kernel(uint32_t *p, size_t n, uint32_t first) { // [first, 0, 1, .., first-1, first+1, ..]
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    p[i] = i == 0 ? first : (i <= first ? (uint32_t)(i - 1) : (uint32_t)i);
-}
-// column means for the Vamana medoid (mean direction): S row-slices x columns partial sums in f64,
-// then a fixed-order reduction over the slices (reproducible).
 __global__ void col_partial_kernel(const float *__restrict__ X, size_t n, uint32_t d, uint32_t ld, uint32_t S,
                                    double *__restrict__ part /* [S x ld] */) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, sl = blockIdx.y;
@@ -379,7 +373,8 @@ struct Builder {
     float *adjd0 = nullptr, *adjdU = nullptr;
     std::vector<uint8_t> levels;     // host copy
     std::vector<uint32_t> upper_off; // host copy
-    uint32_t *d_order = nullptr;     // insertion order
+    uint32_t *d_order = nullptr;     // insertion order (device copy)
+    std::vector<uint32_t> order;     // ... host copy: order[j] = position inserted j-th
     std::vector<uint32_t> h_order_first; // only used for Vamana (medoid first)
     // per-batch scratch
     size_t bmax = 0;
@@ -474,7 +469,7 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
             for (uint32_t l = Lmax; l >= 1; --l) {
                 std::vector<uint32_t> rows;
                 for (size_t i = s; i < s + B; i++)
-                    if (b.levels[i] >= l) rows.push_back((uint32_t)i); // HNSW order is the identity
+                    if (b.levels[b.order[i]] >= l) rows.push_back(b.order[i]);
                 if (rows.empty()) continue;
                 if (offU + rows.size() > bu_cap) {
                     leann_set_error("build: upper-level scratch exhausted");
@@ -524,11 +519,37 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
         // ---- entry point / top level (sequential semantics of hnsw.rs:128-130 within the batch) --
         if (hnsw)
             for (size_t i = s; i < s + B; i++)
-                if (b.levels[i] > h->g.max_level) { h->g.max_level = b.levels[i]; h->g.entry = (uint32_t)i; }
+                if (b.levels[b.order[i]] > h->g.max_level) { h->g.max_level = b.levels[b.order[i]]; h->g.entry = b.order[i]; }
         s += B;
     }
     BCHECK(hipStreamSynchronize(b.st));
     return LEANN_OK;
+}
+
+// Insertion order.  A batch is inserted against the graph of the batches before it (its points do not see each other), so every
+// batch must be a representative sample of the rows still to come: inserting in storage order breaks on data stored topic by topic
+// (a 10M-row corpus laid out cluster-major and built in id order: recall@10 0.20 at ef = 56, against 0.957 for the same rows stored
+// in hashed order).  The rows [lo, n) are therefore inserted in a fixed pseudo-random permutation (positions sorted by a hash of
+// the position): 0.957 for both layouts.  (A golden-ratio stride permutation was tried first: fine on the cluster-major layout,
+// 0.947 on the hashed one.)  Rows [0, lo) (an existing index) keep their places.  `pin_first`: that position is inserted first
+// (Vamana medoid).  Returns order[lo].
+static uint32_t insertion_order(std::vector<uint32_t> &order, size_t lo, size_t n, const uint32_t *pin_first = nullptr) {
+    order.resize(std::max<size_t>(n, 1));
+    for (size_t i = 0; i < lo; i++) order[i] = (uint32_t)i;
+    const uint64_t m = n - lo;
+    if (m == 0) return 0;
+    size_t w = lo;
+    if (pin_first) order[w++] = *pin_first;
+    // pseudo-random permutation: positions sorted by a hash of the position (ties impossible: the position is part of the key)
+    std::vector<uint64_t> keyed(m);
+    for (uint64_t j = 0; j < m; j++) keyed[j] = (mix64((lo + j) ^ 0x4F52444552ull) & 0xFFFFFFFF00000000ull) | (uint32_t)(lo + j);
+    std::sort(keyed.begin(), keyed.end());
+    for (uint64_t j = 0; j < m; j++) {
+        const uint32_t pos = (uint32_t)keyed[j];
+        if (pin_first && pos == *pin_first) continue;
+        order[w++] = pos;
+    }
+    return order[lo];
 }
 
 static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint) {
@@ -577,17 +598,19 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
             first = (uint32_t)key;
             (void)hipFree(mean); (void)hipFree(mk); (void)hipFree(ms); (void)hipFree(mc);
         }
-        hipLaunchKernelGGL(iota_skip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b.st, b.d_order, n, first);
+        if (h->kind == LEANN_BACKEND_HNSW) first = insertion_order(b.order, 0, n);
+        else insertion_order(b.order, 0, n, &first);
         h->g.entry = first;
-        h->g.max_level = h->kind == LEANN_BACKEND_HNSW ? b.levels[0] : 0;
+        h->g.max_level = h->kind == LEANN_BACKEND_HNSW ? b.levels[first] : 0;
         s0 = 1;
     } else {
-        hipLaunchKernelGGL(iota_skip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b.st, b.d_order, n, 0u);
+        insertion_order(b.order, n_existing, n);
         // append: the existing links' stored distances (read by reverse_merge_kernel when a list is pruned)
         hipLaunchKernelGGL(link_dist_kernel, dim3((unsigned)((n_existing + 3) / 4)), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, h->d_levels,
                            (uint32_t)n_existing);
         BCHECK(hipGetLastError());
     }
+    BCHECK(hipMemcpyAsync(b.d_order, b.order.data(), n * 4, hipMemcpyHostToDevice, b.st));
     size_t bmax = bmax_hint ? bmax_hint : 16384;
     rc = builder_alloc_scratch(b, bmax);
     if (rc == LEANN_OK) rc = builder_insert_range(b, {}, s0, n);

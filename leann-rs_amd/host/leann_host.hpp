@@ -497,14 +497,14 @@ class IndexSearcher {
             // every returned position already passes the filter, so no over-fetch is needed for it
             if (!opts.hybrid) { fetch_k = opts.top_k; }
             const std::vector<uint8_t> &bm = allow_bitmap(*opts.filter, opts.filter_key);
-            // The answer comes from the pool of evaluated nodes (~33 x complexity at M = 32): widen the walk so that the pool is
-            // expected to hold >= 8 x fetch_k allowed passages (selectivity s: complexity >= 8 fetch_k / (33 s)), capped at 1024.
+            // The answer comes from the pool of evaluated nodes (20-33 x complexity for M = 16-32): widen the walk so that the pool is
+            // expected to hold >= 8 x fetch_k allowed passages (selectivity s: complexity >= 8 fetch_k / (20 s)), capped at 1024.
             size_t allowed = 0;
             for (uint8_t b : bm) allowed += (size_t)__builtin_popcount(b);
             size_t complexity = opts.complexity;
             if (allowed > 0) {
                 const double s_sel = (double)allowed / (double)std::max<size_t>(leann_backend_len(backend_.get()), 1);
-                complexity = std::min<size_t>(1024, std::max<size_t>(complexity, (size_t)std::ceil(8.0 * (double)fetch_k / (33.0 * s_sel))));
+                complexity = std::min<size_t>(1024, std::max<size_t>(complexity, (size_t)std::ceil(8.0 * (double)fetch_k / (20.0 * s_sel))));
             }
             check(leann_backend_search_filtered(backend_.get(), query_embedding.data(), fetch_k, complexity, bm.data(),
                                                 keys.data(), dists.data(), &n));

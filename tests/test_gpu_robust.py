@@ -87,8 +87,8 @@ def test_degenerate_sizes(la, po, gpu, tmp_path):
 
 def test_add_to_index_equals_one_shot_build(la, po, gpu, tmp_path):
     """add_to_index appends to the loaded graph (hnsw.rs:142-191): the new rows continue the batched insertion from the saved state
-    (stored link distances recomputed).  With coinciding batch boundaries (n0 a power of two) the result is the one-shot graph,
-    bit for bit; otherwise it is the same algorithm on another batch schedule: invariants + recall."""
+    (stored link distances recomputed).  The insertion order is a pseudo-random permutation of the rows being added, so an append is the same
+    algorithm on another schedule than a one-shot build of the concatenation: same vectors and levels, valid lists, same recall."""
     d = 64
     Q = synth(po, 100, d, stream=1)
     B = la.BackendBuilder(la.BackendType.Hnsw)
@@ -108,15 +108,11 @@ def test_add_to_index_equals_one_shot_build(la, po, gpu, tmp_path):
         ka, da, _ = sa.search_batch(Q, 10, 64)
         kb, db, _ = sb.search_batch(Q, 10, 64)
         truth = po.exact_topk(X, Q, 10)
-        if case == 0:
-            assert (ga["adj0"] == gb["adj0"]).all() and (ga["adjU"] == gb["adjU"]).all() and ga["entry"] == gb["entry"]
-            assert (ka == kb).all() and (da == db).all()
-        else:
-            a0 = ga["adj0"]
-            valid = a0 != 0xFFFFFFFF
-            assert (a0[valid] < n0 + n1).all() and valid.sum(1).min() >= 1
-            assert (valid[:, :-1] >= valid[:, 1:]).all()  # compact lists
-            assert abs(recall_at_k(ka, truth) - recall_at_k(kb, truth)) <= 0.02
+        a0 = ga["adj0"]
+        valid = a0 != 0xFFFFFFFF
+        assert (a0[valid] < n0 + n1).all() and valid.sum(1).min() >= 1
+        assert (valid[:, :-1] >= valid[:, 1:]).all()  # compact lists
+        assert abs(recall_at_k(ka, truth) - recall_at_k(kb, truth)) <= 0.02
         assert recall_at_k(ka, truth) >= 0.95
         sa.close(); sb.close()
     # an index whose level table did not come from this builder (oracle graph saved through from_arrays): rebuilt on append
@@ -135,6 +131,25 @@ def test_add_to_index_equals_one_shot_build(la, po, gpu, tmp_path):
     kc, _, _ = sc.search_batch(Q, 10, 64)
     assert recall_at_k(kc, po.exact_topk(X, Q, 10)) >= 0.9
     sc.close()
+
+
+def test_build_does_not_depend_on_storage_order(la, po, gpu):
+    """Rows stored topic by topic (cluster-major) must index as well as the same rows in shuffled order: a batch is inserted against the
+    graph of the batches before it, so the builder inserts in a pseudo-random permutation instead of storage order (in storage order this
+    corpus reached recall@10 0.2)."""
+    n, d, M = 60000, 64, 16
+    X = synth(po, n, d, n_clusters=64)
+    Q = synth(po, 300, d, stream=1, n_clusters=64)
+    centre = np.argmax(X @ X[:64].T, axis=1)          # a cheap cluster label: the closest of the first 64 rows
+    Xs = np.ascontiguousarray(X[np.argsort(centre, kind="stable")])
+    rec = []
+    for rows in (X, Xs):
+        dX = la.DeviceArray.from_host(rows)
+        s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, d, M, 100)
+        k, _, _ = s.search_batch(Q, 10, 64)
+        rec.append(recall_at_k(k, po.exact_topk(rows, Q, 10)))
+        s.close()
+    assert rec[0] >= 0.95 and rec[1] >= 0.95 and abs(rec[0] - rec[1]) <= 0.03, rec
 
 
 def test_build_is_reproducible(la, po, gpu):
