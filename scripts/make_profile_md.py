@@ -50,7 +50,7 @@ Files: `r01_hnsw10m_kernel_stats.csv` (all kernels of the process incl. index co
 
 (The `Calls`/`AverageNs` row also averages the shorter ef-ladder launches; the trace isolates the timed ones. `r01_kernel_trace.csv` is 8 MB and not committed.)
 
-Other operating points of the same kernel (un-profiled bench lines): efc=128 graph, ef=80: 905 k queries/s, recall 0.960, 75.4 %;
+Other operating points of the same kernel (un-profiled bench lines, graphs built before the permuted insertion order): efc=128 graph, ef=80: 905 k queries/s, recall 0.960, 75.4 %;
 efc=128, ef=128 (BASELINE configs[1] beam): 702 k queries/s, recall 0.979, 71.5 %, PMC traffic 0.993x algorithmic.
 
 ## In-kernel stamps (diagnostic build `scripts/stamps.sh`, shares only): cycles per hop seen by wave 0, ef=64, 4M rows
