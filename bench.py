@@ -289,6 +289,9 @@ def main():
     ap.add_argument("--filter-selectivity", type=float, default=0.0,
                     help="side experiment (not the headline metric): metadata-filtered search with a seeded random allow-bitmap "
                          "of this density evaluated inside the traversal; recall is measured against the exact FILTERED top-k")
+    ap.add_argument("--filter-exact", action="store_true",
+                    help="with --filter-selectivity: answer the filtered queries exactly (allowed rows compacted + f32 MFMA scan, "
+                         "leann_backend_search_filtered_exact_batch_device) instead of walking the graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -409,7 +412,9 @@ def main():
         qptr = Q.data_ptr() + qb * B * ld * 4
         if timed_events is not None:
             timed_events[0].record(stream)
-        if allow is not None:
+        if allow is not None and args.filter_exact:
+            searcher.search_filtered_exact_batch_device(qptr, B, k, allow.data_ptr(), 0, keys.data_ptr(), dists.data_ptr(), counts.data_ptr(), sp)
+        elif allow is not None:
             searcher.search_filtered_batch_device(qptr, B, k, ef, allow.data_ptr(), 0, keys.data_ptr(), dists.data_ptr(),
                                                   counts.data_ptr(), stats.data_ptr() + qb * B * 16, sp)
         else:
@@ -452,7 +457,7 @@ def main():
         got = found[:nrq].cpu().numpy()
         return float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(nrq)]))
 
-    if ef_auto:  # "QPS @ recall@10 >= 0.95": the cheapest beam that still meets the recall bar
+    if ef_auto and not (allow is not None and args.filter_exact):  # "QPS @ recall@10 >= 0.95": the cheapest beam that still meets the recall bar
         for cand in (40, 48, 56, 64, 72, 80, 96, 112, 128):
             ef = cand
             if measure_recall() >= 0.955:
@@ -544,6 +549,16 @@ def main():
             "hbm_table_queries": ovf,
         },
     }
+    if allow is not None and args.filter_exact:  # no graph involved: the scan of the allowed rows is bound by the f32 matrix cores
+        n_allowed = int(torch.count_nonzero((allow.view(-1, 1) & wts.view(1, -1)) != 0).item())
+        flops = 2.0 * n_allowed * d * B
+        out["config"]["filter_note"] = ("side experiment: exact filtered search — the %d allowed rows are compacted and scanned "
+                                        "(score_mfma_kernel<true>, candidate emission), no graph walk" % n_allowed)
+        out["config"]["ef_search"] = None
+        out["roofline"] = {"bound": "mfma", "achieved": flops / kern_avg_s / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flops / kern_avg_s / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "kernel": "score_mfma_kernel<true> (+ compaction, fold, finalize inside the HIP-event bracket)",
+                           "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_flops_per_launch": flops, "allowed_rows": n_allowed}
     if shard:
         out["end_to_end_qps"] = B * args.steps / elapsed
         out["config"]["value_unit_note"] = ("value counts query x shard searches (each rank searches every query on its "

@@ -76,6 +76,16 @@ int leann_backend_search_filtered_batch(const leann_backend *h, const float *que
                                         size_t allow_stride, uint64_t *keys, float *dists,
                                         uint32_t *counts);
 
+/* Additive: the same filter answered EXACTLY, for filters that allow only a small share of the rows (a graph walk finds
+ * few allowed nodes then: 1 % allowed -> filtered recall@10 0.86 at complexity 256).  The bitmap is compacted into the
+ * list of allowed positions and only those rows are scanned (f32 matrix cores, one k-ordered fmaf chain per pair, like
+ * leann_scan_topk_device): top_k best allowed positions by distance 1 - <x, q>, ties to the lower position; cost is
+ * proportional to the number of allowed rows, independent of the graph.  The host-side planner
+ * (host/leann_host.hpp IndexSearcher) switches to it below ~2 % allowed.  Needs stored vectors. */
+int leann_backend_search_filtered_exact_batch(const leann_backend *h, const float *queries, size_t nq,
+                                              size_t top_k, const uint8_t *allow, size_t allow_stride,
+                                              uint64_t *keys, float *dists, uint32_t *counts);
+
 /* Additive: request coalescing for servers that call leann_backend_search from many threads (one query per
  * call, src/cli/serve.rs:289-292).  Concurrent callers are gathered for up to wait_us microseconds (or
  * max_batch queries) and answered by one batched launch; results are identical.  (0, 0) disables. */
@@ -148,6 +158,10 @@ int leann_backend_search_filtered_batch_device(const leann_backend *h, const flo
                                                const uint8_t *d_allow, size_t allow_stride,
                                                uint64_t *d_keys, float *d_dists, uint32_t *d_counts,
                                                uint32_t *d_stats, void *stream);
+int leann_backend_search_filtered_exact_batch_device(const leann_backend *h, const float *d_queries,
+                                                     size_t nq, size_t top_k, const uint8_t *d_allow,
+                                                     size_t allow_stride, uint64_t *d_keys, float *d_dists,
+                                                     uint32_t *d_counts, void *stream);
 /* device pointer of the rows (for ground-truth scans) */
 const float *leann_backend_device_rows(const leann_backend *h);
 

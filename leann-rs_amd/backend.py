@@ -134,6 +134,29 @@ class BackendSearcher:
                                                             stride, _p(keys, u64p), _p(dists, f32p), _p(counts, u32p)))
         return keys, dists, counts
 
+    def search_filtered_exact_batch(self, queries, top_k, allow):
+        """exact answer for a selective filter: the allowed rows are compacted and scanned (no graph).  allow as in
+        search_filtered_batch."""
+        Q = np.ascontiguousarray(queries, np.float32)
+        if Q.ndim != 2 or Q.shape[1] != self.dims():
+            raise LeannError(1, f"queries must be [nq x {self.dims()}]")
+        allow = np.ascontiguousarray(allow, np.uint8)
+        stride = 0 if allow.ndim == 1 else allow.shape[1]
+        if allow.shape[-1] < (self.len() + 7) // 8 or (allow.ndim == 2 and allow.shape[0] != Q.shape[0]):
+            raise LeannError(1, "allow-bitmap shape does not match the index / the batch")
+        nq = Q.shape[0]
+        keys = np.full((nq, top_k), np.iinfo(np.uint64).max, np.uint64)
+        dists = np.full((nq, top_k), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        N.check(N.lib().leann_backend_search_filtered_exact_batch(self._h, _p(Q, f32p), nq, top_k, _p(allow, u8p), stride,
+                                                                  _p(keys, u64p), _p(dists, f32p), _p(counts, u32p)))
+        return keys, dists, counts
+
+    def search_filtered_exact_batch_device(self, d_queries, nq, top_k, d_allow, allow_stride, d_keys, d_dists, d_counts,
+                                           stream=None):
+        N.check(N.lib().leann_backend_search_filtered_exact_batch_device(self._h, d_queries, nq, top_k, d_allow, allow_stride,
+                                                                         d_keys, d_dists, d_counts, stream))
+
     def search_batch_device(self, d_queries, nq, top_k, complexity, d_keys, d_dists, d_counts,
                             d_stats=None, stream=None):
         N.check(N.lib().leann_backend_search_batch_device(self._h, d_queries, nq, top_k, complexity,

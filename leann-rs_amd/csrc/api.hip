@@ -315,9 +315,54 @@ extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *
 }
 
 // ... with an optional allow-bitmap over positions (host memory; one shared bitmap when allow_stride == 0)
+static int search_filtered_batch_host(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
+                                      const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, bool exact);
 extern "C" int leann_backend_search_filtered_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k,
                                                    size_t complexity, const uint8_t *allow, size_t allow_stride,
                                                    uint64_t *keys, float *dists, uint32_t *counts) {
+    return search_filtered_batch_host(hc, queries, nq, top_k, complexity, allow, allow_stride, keys, dists, counts, false);
+}
+// ... answered exactly: the allowed rows are compacted and scanned (scan.hip), no graph involved
+extern "C" int leann_backend_search_filtered_exact_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k,
+                                                         const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists,
+                                                         uint32_t *counts) {
+    if (!allow) {
+        leann_set_error("leann_backend_search_filtered_exact_batch: null allow-bitmap");
+        return LEANN_ERR_INVALID;
+    }
+    return search_filtered_batch_host(hc, queries, nq, top_k, 0, allow, allow_stride, keys, dists, counts, true);
+}
+int leann_internal_filtered_exact(const float *d_rows, size_t n, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t top_k,
+                                  const uint8_t *d_allow, size_t allow_stride, uint64_t key_offset, uint64_t *d_keys, float *d_dists,
+                                  uint32_t *d_counts, hipStream_t st);
+extern "C" int leann_backend_search_filtered_exact_batch_device(const leann_backend *hc, const float *d_queries, size_t nq, size_t top_k,
+                                                                const uint8_t *d_allow, size_t allow_stride, uint64_t *d_keys,
+                                                                float *d_dists, uint32_t *d_counts, void *stream) {
+    leann_backend *h = const_cast<leann_backend *>(hc);
+    if (!h || !d_queries || !d_keys || !d_dists || !d_counts || !d_allow || top_k == 0) {
+        leann_set_error("leann_backend_search_filtered_exact_batch_device: null/zero argument");
+        return LEANN_ERR_INVALID;
+    }
+    if (h->g.feat_h) {
+        leann_set_error("exact filtered search needs stored vectors; this index recomputes them from features (use leann_recompute_search_batch_device with an allow mask)");
+        return LEANN_ERR_UNSUPPORTED;
+    }
+    if (allow_stride && allow_stride < (h->g.n + 7) / 8) {
+        leann_set_error("filtered search: allow_stride %zu is smaller than the %zu-byte bitmap", allow_stride, (size_t)(h->g.n + 7) / 8);
+        return LEANN_ERR_INVALID;
+    }
+    if (nq == 0) return LEANN_OK;
+    HIP_CHECK_RET(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->g.n == 0) {
+        HIP_CHECK_RET(hipMemsetAsync(d_counts, 0, nq * 4, st));
+        return LEANN_OK;
+    }
+    return leann_internal_filtered_exact(h->g.X, h->g.n, h->g.d, h->g.ld, d_queries, nq, top_k, d_allow, allow_stride, h->key_offset, d_keys,
+                                         d_dists, d_counts, st);
+}
+static int search_filtered_batch_host(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
+                                      const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, bool exact) {
     leann_backend *h = const_cast<leann_backend *>(hc);
     if (!h || !queries || !keys || !dists || !counts) {
         leann_set_error("leann_backend_search_batch: null argument");
@@ -392,7 +437,17 @@ extern "C" int leann_backend_search_filtered_batch(const leann_backend *hc, cons
     a.out_stats = w->d_stats;
     a.allow = allow ? w->d_allow : nullptr;
     a.allow_stride = allow_stride;
-    rc = leann_internal_launch_search(h, a, st);
+    if (exact) {
+        if (h->g.feat_h) {
+            leann_set_error("exact filtered search needs stored vectors; this index recomputes them from features");
+            return fail(LEANN_ERR_UNSUPPORTED);
+        }
+        if (hipMemsetAsync(w->d_stats, 0, nq * 16, st) != hipSuccess) return fail(LEANN_ERR_DEVICE);
+        rc = leann_internal_filtered_exact(h->g.X, h->g.n, h->g.d, h->g.ld, w->d_q, nq, top_k, w->d_allow, allow_stride, h->key_offset,
+                                           w->d_keys, w->d_dists, w->d_counts, st);
+    } else {
+        rc = leann_internal_launch_search(h, a, st);
+    }
     if (rc) return fail(rc);
     std::vector<uint32_t> hstats(nq * 4);
     if (hipMemcpyAsync(keys, w->d_keys, no * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

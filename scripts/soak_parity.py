@@ -34,8 +34,14 @@ for c in range(n_cfg):
     fk, fd, fc, _ = G.search_filtered_batch(Q, k, ef, bm, algo, nthreads=8)
     hk, hd, hc = s.search_filtered_batch(Q, k, ef, bm)
     same_f = (hk == fk).all() and (hd.view(np.uint32) == fd.view(np.uint32)).all() and (hc == fc).all()
-    print(f"cfg {c:2d}: n={n} d={d} M={M} ef={ef} k={k} nq={nq} r={r} {'vamana' if vam else 'hnsw'}: search {'ok' if same else 'MISMATCH'}, filtered {'ok' if same_f else 'MISMATCH'}", flush=True)
-    bad += (not same) + (not same_f)
+    # exact filtered search (compacted allowed rows + f32 MFMA scan) vs the oracle's sequential-fmaf scan with the early filter
+    xk, xd, xc = s.search_filtered_exact_batch(Q, k, bm)
+    same_x = True
+    for i in range(min(nq, 40)):
+        rk, rs = po.scan_topk(X, Q[i], k, mode=1, allow_mask=bm)
+        same_x &= xc[i] == len(rk) and (xk[i, : len(rk)] == rk).all() and (xd[i, : len(rk)].view(np.uint32) == (np.float32(1.0) - rs).view(np.uint32)).all()
+    print(f"cfg {c:2d}: n={n} d={d} M={M} ef={ef} k={k} nq={nq} r={r} {'vamana' if vam else 'hnsw'}: search {'ok' if same else 'MISMATCH'}, filtered {'ok' if same_f else 'MISMATCH'}, exact-filtered {'ok' if same_x else 'MISMATCH'}", flush=True)
+    bad += (not same) + (not same_f) + (not same_x)
     s.close()
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -113,7 +113,7 @@ def test_device_filter_flag(index_dir):
     assert post.returncode == 0 and dev.returncode == 0, dev.stderr
     rp, rd = json.loads(post.stdout), json.loads(dev.stdout)
     assert all(x["metadata"]["lines"] < 12 for x in rp + rd)
-    assert len(rd) >= max(len(rp), 4)
+    assert len(rd) == 6  # 12 passages pass the filter; a filter this selective is answered exactly (allowed rows scanned)
     sd = [x["score"] for x in rd]
     assert sd == sorted(sd)
     for a, b in zip(rp, rd):  # never worse than post-filtering

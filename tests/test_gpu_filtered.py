@@ -141,3 +141,70 @@ def test_filtered_recompute_on_graph(la, po, gpu):
             assert allowed[gk[i, : gc[i]].astype(np.int64)].all()
     s.close()
     Lc.leann_recompute_close(r)
+
+
+# ---- the selective end: exact filtered search (compacted allowed rows + f32 MFMA scan) --------------------------------------
+
+def _exact_oracle(po, X, Q, k, bm):
+    """oracle/oracle.c:orc_scan_topk with the sequential fmaf dot (mode 1) and the early filter of recompute.rs:66-71;
+    distance = 1 - score as the backends report it."""
+    n_q = len(Q)
+    keys = np.full((n_q, k), np.iinfo(np.uint64).max, np.uint64)
+    dists = np.full((n_q, k), np.inf, np.float32)
+    counts = np.zeros(n_q, np.uint32)
+    for i in range(n_q):
+        b = bm if bm.ndim == 1 else bm[i]
+        kk, ss = po.scan_topk(X, Q[i], k, mode=1, allow_mask=b)
+        keys[i, : len(kk)], dists[i, : len(kk)], counts[i] = kk, np.float32(1.0) - ss, len(kk)
+    return keys, dists, counts
+
+
+@pytest.mark.parametrize("n,d,nq", [(20000, 96, 70), (5000, 50, 9), (150000, 64, 33)])
+def test_filtered_exact_matches_oracle(la, po, gpu, n, d, nq):
+    rng = np.random.default_rng(n + d)
+    X = synth(po, n, d)
+    Q = synth(po, nq, d, stream=1)
+    ld = (d + 3) // 4 * 4                    # device rows are 16-byte aligned, zero padded
+    Xp = np.zeros((n, ld), np.float32)
+    Xp[:, :d] = X
+    dX = la.DeviceArray.from_host(Xp)
+    off = 1000
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, ld, 8, 32, key_offset=off)
+    for sel in (0.6, 0.05, 0.004):           # 150k x 0.6 = 90k listed rows: the emission pass of the scan runs over a row list
+        bm, allowed = _bitmap(rng, n, sel)
+        for k in (10, 1, 100):
+            ok, od, oc = _exact_oracle(po, X, Q, k, bm)
+            gk, gd, gc = s.search_filtered_exact_batch(Q, k, bm)
+            assert (gc == oc).all()
+            live = ok != np.iinfo(np.uint64).max
+            assert (gk[live] == ok[live] + np.uint64(off)).all() and (gk[~live] == np.iinfo(np.uint64).max).all()
+            assert (gd.view(np.uint32) == od.view(np.uint32)).all()   # same fmaf chain, same 1 - s: bit for bit
+    # one bitmap per query; a query with an empty filter; a filter with fewer allowed rows than k
+    bmq, allowed_q = _bitmap(rng, n, 0.01, nq=nq)
+    bmq[1] = 0
+    bmq[2] = 0
+    bmq[2, 5] = 0b00010010  # positions 41 and 44
+    ok, od, oc = _exact_oracle(po, X, Q, 10, bmq)
+    gk, gd, gc = s.search_filtered_exact_batch(Q, 10, bmq)
+    assert gc[1] == 0 and gc[2] == 2 and set(gk[2, :2].tolist()) == {41 + off, 44 + off}
+    assert (gc == oc).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    live = ok != np.iinfo(np.uint64).max
+    assert (gk[live] == ok[live] + np.uint64(off)).all()
+    # device-pointer twin
+    bm, _ = _bitmap(rng, n, 0.02)
+    hk, hd, hc = s.search_filtered_exact_batch(Q, 10, bm)
+    dQ, dB = la.DeviceArray.from_host(Q), la.DeviceArray.from_host(bm)
+    dk, dd, dc = la.DeviceArray((nq, 10), np.uint64), la.DeviceArray((nq, 10), np.float32), la.DeviceArray(nq, np.uint32)
+    s.search_filtered_exact_batch_device(dQ.ptr, nq, 10, dB.ptr, 0, dk.ptr, dd.ptr, dc.ptr)
+    la.sync()
+    assert (dk.to_host() == hk).all() and (dd.to_host().view(np.uint32) == hd.view(np.uint32)).all() and (dc.to_host() == hc).all()
+    # it beats the walk where the walk starves: recall of the exact path is 1 by construction, the traversal's is not
+    bm, allowed = _bitmap(rng, n, 0.004)
+    ek, _, _ = s.search_filtered_exact_batch(Q, 10, bm)
+    wk, _, _ = s.search_filtered_batch(Q, 10, 64, bm)
+    assert recall_at_k(wk, ek) <= 1.0
+    with pytest.raises(la.LeannError):
+        s.search_filtered_exact_batch(Q, 10, bm[:-3])
+    with pytest.raises(la.LeannError):
+        s.search_filtered_exact_batch(Q, 5000, bm)
+    s.close()
