@@ -81,7 +81,7 @@ int leann_backend_search_filtered_batch(const leann_backend *h, const float *que
  * list of allowed positions and only those rows are scanned (f32 matrix cores, one k-ordered fmaf chain per pair, like
  * leann_scan_topk_device): top_k best allowed positions by distance 1 - <x, q>, ties to the lower position; cost is
  * proportional to the number of allowed rows, independent of the graph.  The host-side planner
- * (host/leann_host.hpp IndexSearcher) switches to it below ~2 % allowed.  Needs stored vectors. */
+ * (host/leann_host.hpp IndexSearcher) switches to it below 5 % allowed (single queries; ~1.5 % is the crossover in 16k-query batches).  Needs stored vectors. */
 int leann_backend_search_filtered_exact_batch(const leann_backend *h, const float *queries, size_t nq,
                                               size_t top_k, const uint8_t *allow, size_t allow_stride,
                                               uint64_t *keys, float *dists, uint32_t *counts);

@@ -33,7 +33,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // LIST: row i of the launch is X[idx[i]] (exact search over the allowed positions of a filter, compacted ascending by
 // compact_allow below); scores, slab columns and emitted keys are then indexed by i, and finalize_scan_kernel maps i -> idx[i].
-template <bool LIST>
+// FAST (dims a multiple of the 32-wide k-tile, 16-byte aligned rows and queries): the six 16-byte loads of a k-tile are unconditional —
+// rows / queries past the end are clamped to the last valid one, their scores are never stored — so they issue back to back.  The
+// general path's bounds / alignment branches made hipcc wait for each load before issuing the next (same registers for address and
+// data): 6 memory round trips per k-tile in front of the MFMA loop.
+template <bool LIST, bool FAST>
 __global__ void __launch_bounds__(256) score_mfma_kernel(const float *__restrict__ X, uint64_t n, uint32_t d,
                                                          uint32_t ld, const float *__restrict__ Q, uint32_t nq,
                                                          uint32_t ldq, uint64_t row0, uint32_t n_rows,
@@ -71,23 +75,40 @@ __global__ void __launch_bounds__(256) score_mfma_kernel(const float *__restrict
     };
     float4 xv[4], qv[2]; // the next k-tile travels in registers while the current one is multiplied
     uint32_t xrow[4];    // LIST: the positions of this thread's four rows
-    if constexpr (LIST) {
+    if constexpr (LIST && !FAST) {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const uint32_t row = rbase + sr + 32 * p;
             xrow[p] = row < n_rows ? idx[row0 + row] : 0u;
         }
     }
-    auto gload = [&](uint32_t k0) {
+    const float *xp[4], *qp[2]; // FAST: this thread's four rows and two queries at its k offset
+    if constexpr (FAST) {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const uint32_t row = rbase + sr + 32 * p;
-            xv[p] = load4(X + (LIST ? (size_t)xrow[p] : (size_t)(row0 + row)) * ld, row < n_rows, xvec, k0 + kq, d);
+            const uint32_t row = min(rbase + sr + 32 * p, n_rows - 1);
+            xp[p] = X + (LIST ? (size_t)idx[row0 + row] : (size_t)(row0 + row)) * ld + kq;
         }
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const uint32_t qi = qbase + sr + 32 * p;
-            qv[p] = load4(Q + (size_t)qi * ldq, qi < nq, qvec, k0 + kq, d);
+        for (int p = 0; p < 2; p++) qp[p] = Q + (size_t)min(qbase + sr + 32 * p, nq - 1) * ldq + kq;
+    }
+    auto gload = [&](uint32_t k0) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) xv[p] = *reinterpret_cast<const float4 *>(xp[p] + k0);
+#pragma unroll
+            for (int p = 0; p < 2; p++) qv[p] = *reinterpret_cast<const float4 *>(qp[p] + k0);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t row = rbase + sr + 32 * p;
+                xv[p] = load4(X + (LIST ? (size_t)xrow[p] : (size_t)(row0 + row)) * ld, row < n_rows, xvec, k0 + kq, d);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint32_t qi = qbase + sr + 32 * p;
+                qv[p] = load4(Q + (size_t)qi * ldq, qi < nq, qvec, k0 + kq, d);
+            }
         }
     };
     auto lstore = [&]() {
@@ -275,13 +296,26 @@ __global__ void finalize_scan_kernel(const uint64_t *__restrict__ keys, uint32_t
     }
 }
 
+
+// one launch of score_mfma_kernel (row list optional); picks the FAST instantiation when the shapes allow
+static void launch_score(hipStream_t st, const float *X, size_t rows, size_t dims, size_t ld, const float *Q, size_t nq, size_t ldq, float *S,
+                         const CandEmit &em, const uint32_t *idx) {
+    dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
+    const bool fast = dims % 32 == 0 && ld % 4 == 0 && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(Q) & 15) == 0 && rows > 0 && nq > 0;
+#define LEANN_SCORE_LAUNCH(LIST_, FAST_)                                                                                                  \
+    hipLaunchKernelGGL((score_mfma_kernel<LIST_, FAST_>), g1, dim3(256), 0, st, X, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld, Q,       \
+                       (uint32_t)nq, (uint32_t)ldq, (uint64_t)0, (uint32_t)rows, S, em, idx)
+    if (idx) { if (fast) LEANN_SCORE_LAUNCH(true, true); else LEANN_SCORE_LAUNCH(true, false); }
+    else { if (fast) LEANN_SCORE_LAUNCH(false, true); else LEANN_SCORE_LAUNCH(false, false); }
+#undef LEANN_SCORE_LAUNCH
+}
+
 // S[q][row] = <X[row], Q[q]> for all rows (k-ordered f32 fmaf chains on the f32 matrix cores); also used to project
 // queries into feature space (X = encoder weights) for the recompute-on graph search
 int leann_internal_score(const float *X, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t ldq, float *S,
                          hipStream_t st) {
-    dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
-    hipLaunchKernelGGL(score_mfma_kernel<false>, g1, dim3(256), 0, st, X, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld, d_queries, (uint32_t)nq,
-                       (uint32_t)ldq, (uint64_t)0, (uint32_t)rows, S, CandEmit{}, (const uint32_t *)nullptr);
+    launch_score(st, X, rows, dims, ld, d_queries, nq, ldq, S, CandEmit{}, nullptr);
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
 }
@@ -293,13 +327,7 @@ int leann_internal_scan_chunk(const float *Xbase, size_t rows, size_t dims, size
                               const uint8_t *allow, uint64_t pos0, float *S, uint64_t *cand, size_t cand_len, size_t seg_off,
                               hipStream_t st, size_t *segs_out, hipEvent_t mid = nullptr, uint64_t *best = nullptr,
                               const uint32_t *idx = nullptr) {
-    dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
-    if (idx)
-        hipLaunchKernelGGL(score_mfma_kernel<true>, g1, dim3(256), 0, st, Xbase, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld, d_queries,
-                           (uint32_t)nq, (uint32_t)dims, (uint64_t)0, (uint32_t)rows, S, CandEmit{}, idx);
-    else
-        hipLaunchKernelGGL(score_mfma_kernel<false>, g1, dim3(256), 0, st, Xbase, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld, d_queries,
-                           (uint32_t)nq, (uint32_t)dims, (uint64_t)0, (uint32_t)rows, S, CandEmit{}, (const uint32_t *)nullptr);
+    launch_score(st, Xbase, rows, dims, ld, d_queries, nq, dims, S, CandEmit{}, idx);
     if (mid) (void)hipEventRecord(mid, st);
     unsigned segs = (unsigned)((rows + SEG - 1) / SEG);
     hipLaunchKernelGGL(topk_scores_kernel, dim3(segs, (unsigned)nq), dim3(256), 0, st, S, (uint32_t)rows, pos0, allow, k, cand,
@@ -442,14 +470,7 @@ static int scan_topk_impl(const float *d_rows, size_t n, size_t dims, size_t ld,
             size_t segs = 0;
             if (emit && c > 0) {
                 em.pos0 = row0;
-                dim3 g1((unsigned)((rows + 127) / 128), (unsigned)((nq + 63) / 64));
-                if (idx)
-                    hipLaunchKernelGGL(score_mfma_kernel<true>, g1, dim3(256), 0, st, d_rows, (uint64_t)rows, (uint32_t)dims, (uint32_t)ld,
-                                       d_queries, (uint32_t)nq, (uint32_t)dims, (uint64_t)0, (uint32_t)rows, S, em, idx + row0);
-                else
-                    hipLaunchKernelGGL(score_mfma_kernel<false>, g1, dim3(256), 0, st, d_rows + row0 * ld, (uint64_t)rows, (uint32_t)dims,
-                                       (uint32_t)ld, d_queries, (uint32_t)nq, (uint32_t)dims, (uint64_t)0, (uint32_t)rows, S, em,
-                                       (const uint32_t *)nullptr);
+                launch_score(st, idx ? d_rows : d_rows + row0 * ld, rows, dims, ld, d_queries, nq, dims, S, em, idx ? idx + row0 : nullptr);
             } else {
                 rc = leann_internal_scan_chunk(idx ? d_rows : d_rows + row0 * ld, rows, dims, ld, d_queries, nq, k, d_allow_mask, row0, S, candA,
                                                cand_len, seg_off, st, &segs, nullptr, (n_chunks > 1 || emit) ? best : nullptr,

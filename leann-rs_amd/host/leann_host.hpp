@@ -507,11 +507,12 @@ class IndexSearcher {
                 const double s_sel = (double)allowed / (double)n_rows;
                 complexity = std::min<size_t>(1024, std::max<size_t>(complexity, (size_t)std::ceil(8.0 * (double)fetch_k / (20.0 * s_sel))));
             }
-            // Selective filters (<= 1.5 % of the rows, or <= 64k rows) are answered exactly: the allowed rows are compacted and
-            // scanned on the device; measured at 10M x 768, 1 % allowed: 443 k QPS at recall 1.0 against 471 k at 0.86 for the
-            // walk with complexity 256 (3 %: 183 k exact, 474 k at 0.94 walking).  Indexes without stored vectors keep walking.
+            // Selective filters (<= 5 % of the rows, or <= 64k rows) are answered exactly: the allowed rows are compacted and scanned on
+            // the device.  One query at a time (this call), 4M x 768 rows (scripts/filter_latency.py): 3 % allowed: 0.62 ms exact against
+            // 0.75 ms walking at recall 0.90; 1 %: 0.34 ms against 1.8 ms at 0.73; 10 %: 0.87 ms against 0.48 ms at 0.94 (the walk
+            // wins from there).  In 16 384-query batches the crossover is ~1.5 %.  Indexes without stored vectors keep walking.
             bool done = false;
-            if (allowed <= std::max<size_t>((size_t)(0.015 * (double)n_rows), 65536) && fetch_k <= 1024) {
+            if (allowed <= std::max<size_t>((size_t)(0.05 * (double)n_rows), 65536) && fetch_k <= 1024) {
                 uint32_t cnt = 0;
                 const int rc = leann_backend_search_filtered_exact_batch(backend_.get(), query_embedding.data(), 1, fetch_k, bm.data(), 0,
                                                                          keys.data(), dists.data(), &cnt);
