@@ -570,6 +570,18 @@ def main():
         out["config"]["value_unit_note"] = ("value counts query x shard searches (each rank searches every query on its "
                                             f"{rows}-row shard); end_to_end_qps = value / n_gpus over the {corpus_total}-row corpus")
 
+    # ---- PCIe-inclusive rate: the same batch through the host-pointer entry point (queries and results in host memory) ----
+    if world == 1 and rank == 0 and allow is None and not rgraph:
+        try:
+            Qh = Q[:B, :d].contiguous().cpu().numpy()
+            searcher.search_batch(Qh, k, ef)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                searcher.search_batch(Qh, k, ef)
+            out["pcie_inclusive_qps"] = 3 * B / (time.perf_counter() - t0)  # leann_backend_search_batch: H2D of 3 KB per query, D2H of the results, one sync
+        except Exception as e:  # noqa: BLE001
+            log("host-pointer timing failed:", e)
+
     # ---- CPU baseline: the oracle (C restatement) walking the SAME graph on the host cores --------
     if world == 1 and not args.no_cpu_baseline and rank == 0 and allow is None:
         try:
