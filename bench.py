@@ -395,9 +395,15 @@ def main():
     else:
         with torch.cuda.stream(stream):
             chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 1, q_first, n_pool * B, Q.data_ptr(), sp))
-    keys = torch.empty((B, k), dtype=torch.int64, device=dev)
-    dists = torch.empty((B, k), dtype=torch.float32, device=dev)
-    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    # two sets of per-shard result buffers: with N > 1 the exchange + merge of step i runs on its own stream while the
+    # traversal of step i + 1 fills the other set (the all-gather is latency-bound, so it is overlapped)
+    kbuf = [torch.empty((B, k), dtype=torch.int64, device=dev) for _ in range(2)]
+    dbuf = [torch.empty((B, k), dtype=torch.float32, device=dev) for _ in range(2)]
+    cbuf = [torch.empty((B,), dtype=torch.int32, device=dev) for _ in range(2)]
+    keys, dists, counts = kbuf[0], dbuf[0], cbuf[0]
+    xstream = torch.cuda.Stream(device=dev)
+    ev_search = [torch.cuda.Event() for _ in range(2)]
+    ev_xdone = [None, None]
     stats = torch.zeros((n_pool, B, 4), dtype=torch.int32, device=dev)
     stream.synchronize()
 
@@ -413,9 +419,13 @@ def main():
         torch.cuda.synchronize()
 
     def search(step, timed_events=None):
-        """one step of the hot path on `stream`"""
+        """one step of the hot path on `stream` (N > 1: + exchange and merge on `xstream`, overlapping the next step's traversal)"""
         qb = step % n_pool
+        b = step & 1 if shard else 0
+        keys, dists, counts = kbuf[b], dbuf[b], cbuf[b]
         qptr = Q.data_ptr() + qb * B * ld * 4
+        if shard and ev_xdone[b] is not None:
+            stream.wait_event(ev_xdone[b])  # the exchange that read this buffer set two steps ago
         if timed_events is not None:
             timed_events[0].record(stream)
         if allow is not None and args.filter_exact:
@@ -430,9 +440,13 @@ def main():
             timed_events[1].record(stream)
         if shard:
             # exchange step (leann-rs_amd/shard.py): all-gather the per-shard lists over RCCL, merge on every rank
-            with torch.cuda.stream(stream):
+            ev_search[b].record(stream)
+            xstream.wait_event(ev_search[b])
+            with torch.cuda.stream(xstream):
                 g_keys, g_dists, g_counts = exchange_topk(keys, dists, counts, world)
-                m_keys, _, _ = hip_merge(g_keys, g_dists, g_counts, k, False, stream.cuda_stream)
+                m_keys, _, _ = hip_merge(g_keys, g_dists, g_counts, k, False, xstream.cuda_stream)
+                ev_xdone[b] = torch.cuda.Event()
+                ev_xdone[b].record(xstream)
             return m_keys
         return keys
 
@@ -453,13 +467,13 @@ def main():
         with torch.cuda.stream(stream):
             gk, gs, gc = exchange_topk(gt_k, gt_s, gt_c, world)
             gt_k, gt_s, gt_c = hip_merge(gk, gs, gc, k, True, stream.cuda_stream)
-        stream.synchronize()
+        stream.synchronize(); xstream.synchronize()
     log(f"exact ground truth for {nrq} queries in {time.time() - t0:.2f}s")
     truth = gt_k.cpu().numpy()
 
     def measure_recall():
         found = search(0)
-        stream.synchronize()
+        stream.synchronize(); xstream.synchronize()
         got = found[:nrq].cpu().numpy()
         return float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(nrq)]))
 
@@ -475,7 +489,7 @@ def main():
     # ---- warmup, then exactly K timed steps between barrier + synchronize -------------------------
     for w in range(args.warmup):
         search(w)
-    stream.synchronize()
+    stream.synchronize(); xstream.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if dist is not None:
         dist.barrier()
@@ -483,7 +497,7 @@ def main():
     t0 = time.perf_counter()
     for s_ in range(args.steps):
         search(s_, ev[s_])
-    stream.synchronize()
+    stream.synchronize(); xstream.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
