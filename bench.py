@@ -102,10 +102,22 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
     ms = (C.c_float * 3)()
     tm = []
+    allow, n_allowed = None, rows
+    if args.filter_selectivity > 0:  # side experiment: the early filter of recompute.rs:62-79 (only the allowed passages are embedded)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x5EED0004 + rank)
+        bits = torch.zeros(((rows + 7) // 8) * 8, dtype=torch.uint8, device=dev)
+        bits[:rows] = (torch.rand(rows, device=dev, generator=gen) < args.filter_selectivity).to(torch.uint8)
+        n_allowed = int(bits.sum(dtype=torch.int64).item())
+        wts = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
+        allow = (bits.view(-1, 8) * wts).sum(1, dtype=torch.int32).to(torch.uint8).contiguous()
+        del bits
+        torch.cuda.synchronize()
 
     def step(i):
         qptr = Q.data_ptr() + (i % 4) * B * ld * 4
-        chk(L.leann_recompute_search_batch_device(r, qptr, B, k, None, keys.data_ptr(), scores.data_ptr(), counts.data_ptr(), sp))
+        chk(L.leann_recompute_search_batch_device(r, qptr, B, k, allow.data_ptr() if allow is not None else None, keys.data_ptr(),
+                                                  scores.data_ptr(), counts.data_ptr(), sp))
         L.leann_recompute_last_timing(r, ms)
         tm.append((ms[0], ms[1], ms[2]))
         if shard:
@@ -154,10 +166,19 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
                       "rows_per_gpu": rows, "dims": d, "feature_dim": h, "batch": B, "top_k": k,
                       "parallelism": "single" if world == 1 else f"shard{world}+rccl_allgather"},
            "roofline": roof}
+    if allow is not None:
+        out["config"]["filter_selectivity"] = args.filter_selectivity
+        out["config"]["filter_note"] = (f"side experiment: early filter (recompute.rs:62-79), {n_allowed} of {rows} passages allowed; "
+                                        "the allowed rows are compacted and only they are embedded (fused_fstat_kernel<16,false,true>); "
+                                        "roofline flops count the allowed rows")
+        roof["allowed_rows"] = n_allowed
+        e2, s2 = 2.0 * n_allowed * h * d, 3 * 2.0 * n_allowed * h * ((B + 31) // 32 * 32)
+        roof.update({"achieved": (e2 + s2) / (enc_ms * 1e-3) / 1e12, "frac": (e2 + s2) / (enc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                     "mfma_flops_per_step": e2 + s2, "kernel": "fused_fstat_kernel<16,false,true> (row list)"})
     if shard:
         out["end_to_end_qps"] = B * steps / elapsed
     # ---- CPU baseline: the oracle's literal recompute.rs:86-109 (embed every passage, dot, sort) on a bounded sample -------
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and allow is None:
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po

@@ -427,8 +427,12 @@ static bool use_fstat(const leann_recompute *r) {
 
 static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st,
                          const uint16_t *Gp = nullptr, uint32_t nq = 0, float *S = nullptr, float *norms = nullptr,
-                         const CandEmit *emit = nullptr) {
+                         const CandEmit *emit = nullptr, const uint32_t *idx = nullptr) {
     const bool fused = Gp != nullptr;
+    if (idx && !(fused && use_fstat(r))) {
+        leann_set_error("recompute: a row list needs the fused feature-stationary kernel");
+        return LEANN_ERR_INVALID;
+    }
     if (fused && use_fstat(r)) {
         // features stationary in registers (the common shape: h = 256, dims = 384 / 768)
         const size_t lds2 = 2 * 16 * 128 * 32 + 4 * 64 * 4 + FSTAT_MAX_QUERIES * 4; // two 64-KiB sub-slice buffers + per-wave norm exchange + thresholds
@@ -436,7 +440,11 @@ static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows,
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device);
         const unsigned grid2 = (unsigned)std::min<uint64_t>(units, (uint64_t)cus);
-        if (r->Ft) {
+        if (idx) { // rows [row0, row0 + rows) of the LIST: passage i = row idx[i] of the row-major features
+            HIP_CHECK_RET(hipFuncSetAttribute((const void *)fused_fstat_kernel<16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL((fused_fstat_kernel<16, false, true>), dim3(grid2), dim3(256), lds2, st, r->F, (uint64_t)rows, r->Wp,
+                               (uint32_t)r->dp, Gp, nq, S, (uint32_t)rows, emit ? *emit : CandEmit{}, idx + row0);
+        } else if (r->Ft) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void *)fused_fstat_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL((fused_fstat_kernel<16, true>), dim3(grid2), dim3(256), lds2, st,
                                reinterpret_cast<const uint16_t *>(r->Ft) + row0 * r->h, (uint64_t)rows, r->Wp, (uint32_t)r->dp, Gp, nq, S,
@@ -639,26 +647,49 @@ int leann_internal_scan_finish(uint64_t *candA, uint64_t *candB, size_t cand_len
 // Per tile of <= 64 queries: G = W Q^T once, then per chunk of passages ONE fused kernel (encode GEMM,
 // row norms, feature-space scoring) + segment top-k; the embeddings are never written anywhere.
 static int recompute_search_impl(const leann_recompute *r, const float *d_queries, size_t nq, size_t top_k, const uint8_t *d_allow_mask,
-                                 uint64_t *d_keys, float *d_scores, uint32_t *d_counts, void *stream, bool emit_ok, bool *overflowed);
+                                 uint64_t *d_keys, float *d_scores, uint32_t *d_counts, void *stream, bool emit_ok, bool *overflowed,
+                                 const uint32_t *idx = nullptr, size_t n_list = 0);
+int leann_internal_scan_finish_ex(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k, uint64_t key_offset,
+                                  uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st, const uint32_t *idx, int as_dist);
+int leann_internal_compact_allow(const uint8_t *d_allow, size_t n, uint32_t **d_list, size_t *n_list, hipStream_t st);
 extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, const float *d_queries, size_t nq, size_t top_k,
                                                    const uint8_t *d_allow_mask, uint64_t *d_keys, float *d_scores,
                                                    uint32_t *d_counts, void *stream) {
-    bool overflowed = false;
-    int rc = recompute_search_impl(r, d_queries, nq, top_k, d_allow_mask, d_keys, d_scores, d_counts, stream, true, &overflowed);
-    // a candidate list overflowed (adversarial score order, e.g. ascending): repeat on the score-slab path
-    if (rc == LEANN_OK && overflowed)
-        rc = recompute_search_impl(r, d_queries, nq, top_k, d_allow_mask, d_keys, d_scores, d_counts, stream, false, &overflowed);
-    return rc;
-}
-static int recompute_search_impl(const leann_recompute *r, const float *d_queries, size_t nq, size_t top_k, const uint8_t *d_allow_mask,
-                                 uint64_t *d_keys, float *d_scores, uint32_t *d_counts, void *stream, bool emit_ok, bool *overflowed) {
     if (!r || !d_queries || !d_keys || !d_scores || !d_counts || top_k == 0 || top_k > 1024) {
         leann_set_error("leann_recompute_search_batch_device: invalid arguments");
         return LEANN_ERR_INVALID;
     }
     if (nq == 0) return LEANN_OK;
     HIP_CHECK_RET(hipSetDevice(r->device));
+    // The early filter of recompute.rs:62-79: the reference fetches, and therefore embeds, only the passages that pass the filter.
+    // A selective mask is compacted into the list of allowed positions and only those rows go through the fused kernel (same
+    // per-passage arithmetic, so the same scores as the masked pass over everything); LEANN_RECOMPUTE_NO_LIST=1 keeps the masked pass.
+    uint32_t *list = nullptr;
+    size_t n_list = 0;
+    if (d_allow_mask && use_fstat(r) && r->n < (1ull << 32) && !getenv("LEANN_RECOMPUTE_NO_LIST")) {
+        int rc = leann_internal_compact_allow(d_allow_mask, r->n, &list, &n_list, (hipStream_t)stream);
+        if (rc != LEANN_OK) return rc;
+        if (n_list > r->n / 2) { // barely selective: the masked pass reads the fragment-major feature copy and skips the gather
+            (void)hipFree(list);
+            list = nullptr;
+        } else if (!list) { // nothing allowed: an empty list still needs a non-null marker for the list path
+            HIP_CHECK_RET(hipMalloc((void **)&list, 4));
+        }
+    }
+    bool overflowed = false;
+    int rc = recompute_search_impl(r, d_queries, nq, top_k, d_allow_mask, d_keys, d_scores, d_counts, stream, true, &overflowed, list, n_list);
+    // a candidate list overflowed (adversarial score order, e.g. ascending): repeat on the score-slab path
+    if (rc == LEANN_OK && overflowed)
+        rc = recompute_search_impl(r, d_queries, nq, top_k, d_allow_mask, d_keys, d_scores, d_counts, stream, false, &overflowed, list, n_list);
+    if (list) (void)hipFree(list); // recompute_search_impl synchronises the stream before it returns
+    return rc;
+}
+static int recompute_search_impl(const leann_recompute *r, const float *d_queries, size_t nq, size_t top_k, const uint8_t *d_allow_mask,
+                                 uint64_t *d_keys, float *d_scores, uint32_t *d_counts, void *stream, bool emit_ok, bool *overflowed,
+                                 const uint32_t *idx, size_t n_list) {
     hipStream_t st = (hipStream_t)stream;
+    const size_t N = idx ? n_list : r->n; // passages of this search (idx: the allowed ones, keys are list indices until the finalize step)
+    if (idx) d_allow_mask = nullptr;
     const uint32_t k = (uint32_t)top_k;
     const size_t SEGSZ = 2048;
     // slab path: geometric chunk schedule 128k, 512k, 2M, 4M, 4M ... : the first small chunks fix the running k-th best, after
@@ -669,11 +700,11 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
         // tighten it (~k * 496k / 16k survivors per query), everything else goes through ONE persistent launch
         const bool emit_schedule = emit_ok && use_fstat(r) && !getenv("LEANN_DEBUG_NO_EMIT");
         size_t pos = 0, len = emit_schedule ? (size_t)16 << 10 : (size_t)128 << 10;
-        while (pos < r->n) {
-            size_t rows = std::min(len, r->n - pos);
+        while (pos < N) {
+            size_t rows = std::min(len, N - pos);
             chunks.emplace_back(pos, rows);
             pos += rows;
-            if (emit_schedule) len = chunks.size() == 1 ? (size_t)496 << 10 : r->n;
+            if (emit_schedule) len = chunks.size() == 1 ? (size_t)496 << 10 : N;
             else len = std::min<size_t>(len * 4, (size_t)4 << 20);
         }
     }
@@ -685,7 +716,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     const size_t cand_len = std::max<size_t>(total_segs * k, k);
     leann_recompute *rw = const_cast<leann_recompute *>(r);
     std::lock_guard<std::mutex> scratch_lock(rw->mu);
-    if (use_fstat(r) && !rw->Ft && r->n >= 4096 && !getenv("LEANN_RECOMPUTE_NO_TILED")) {
+    if (use_fstat(r) && !idx && !rw->Ft && r->n >= 4096 && !getenv("LEANN_RECOMPUTE_NO_TILED")) {
         // first exhaustive search on this handle: keep a fragment-major copy of the features (+ n * h * 2 bytes; if HBM is short
         // the kernel reads the caller's row-major array instead, ~10 % slower)
         const uint64_t n_pad = (r->n + 255) / 256 * 256 + 256;
@@ -745,7 +776,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
             (void)hipEventRecord(evs[ei++], st);
             const bool emit_chunk = emit && c > 0;
             em.pos0 = row0;
-            rc = launch_encode(r, row0, rows, nullptr, st, Gp, nqt, S, nullptr, emit_chunk ? &em : nullptr);
+            rc = launch_encode(r, row0, rows, nullptr, st, Gp, nqt, S, nullptr, emit_chunk ? &em : nullptr, idx);
             (void)hipEventRecord(evs[ei++], st);
             size_t segs = 0;
             if (rc == LEANN_OK && !emit_chunk)
@@ -759,8 +790,8 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     }
     if (rc == LEANN_OK) {
         // `best` is the exact running top-k; without emission the final answer is re-derived from all segment winners
-        if (emit) rc = leann_internal_scan_finish(best, candB, k, 1, nq, k, r->key_offset, d_keys, d_scores, d_counts, st);
-        else rc = leann_internal_scan_finish(candA, candB, cand_len, total_segs, nq, k, r->key_offset, d_keys, d_scores, d_counts, st);
+        if (emit) rc = leann_internal_scan_finish_ex(best, candB, k, 1, nq, k, r->key_offset, d_keys, d_scores, d_counts, st, idx, 0);
+        else rc = leann_internal_scan_finish_ex(candA, candB, cand_len, total_segs, nq, k, r->key_offset, d_keys, d_scores, d_counts, st, idx, 0);
     }
     (void)hipEventRecord(evs[ei], st);
     (void)hipStreamSynchronize(st);

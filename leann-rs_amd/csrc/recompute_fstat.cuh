@@ -167,10 +167,15 @@ __global__ void tile_features_kernel(const uint16_t *__restrict__ F, uint64_t n,
     }
 }
 
-template <int KS, bool TILED>
+// LIST (row-major features only): passage i of the launch is row idx[i] of F — the early filter of recompute.rs:62-79 (only the
+// passages that pass the filter are embedded), with the allowed positions compacted ascending by scan.hip:compact_allow.  Slab
+// columns and emitted keys are list indices; the finalize step maps them back to positions.
+template <int KS, bool TILED, bool LIST = false>
 __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__restrict__ F, uint64_t n, const uint16_t *__restrict__ Wp,
                                                           uint32_t dp, const uint16_t *__restrict__ Gp, uint32_t nq,
-                                                          float *__restrict__ S, uint32_t n_rows_s, CandEmit em) {
+                                                          float *__restrict__ S, uint32_t n_rows_s, CandEmit em,
+                                                          const uint32_t *__restrict__ idx = nullptr) {
+    static_assert(!(TILED && LIST), "a row list gathers from the row-major features");
     constexpr int NWV = 4, RB = LEANN_FSTAT_RB; // waves per workgroup, 32-passage blocks per wave
     constexpr int SUB = 128;             // columns per W sub-slice (4 MFMA tiles)
     constexpr int KSB = SUB * 32;        // bytes of one k-step of a sub-slice (4 KiB)
@@ -220,11 +225,23 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     };
     const uint32_t fro = (uint32_t)((2 * l31 + lh) ^ (((2 * l31 + lh) >> 4) & 1)) * 16; // fragment of column l31 within a 32-column tile
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    uint32_t lrow[RB]; // LIST: the rows of F behind this lane's passages of the unit whose features are loaded next
+    auto set_lrow = [&](uint64_t prow0) {
+        if constexpr (LIST) {
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                const uint64_t row = prow0 + rb * 32 + l31;
+                lrow[rb] = idx[row < n ? row : n - 1];
+            }
+        }
+    };
     auto load_features = [&](bf16x8 (&a)[RB][KS], uint64_t prow0, int ks) {
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
             if constexpr (TILED) { // F = fragment-major copy: one contiguous KiB per (block of 32 rows, k-step), padded to whole units
                 a[rb][ks] = reinterpret_cast<const bf16x8 *>(F)[((prow0 / 32 + rb) * KS + ks) * 64 + lane];
+            } else if constexpr (LIST) {
+                a[rb][ks] = *reinterpret_cast<const bf16x8 *>(F + (uint64_t)lrow[rb] * H + ks * 16 + lh * 8);
             } else { // row-major; branch-free: rows past the end re-read the last row (their results are never stored or emitted)
                 const uint64_t row = prow0 + rb * 32 + l31;
                 a[rb][ks] = *reinterpret_cast<const bf16x8 *>(F + (row < n ? row : n - 1) * H + ks * 16 + lh * 8);
@@ -237,6 +254,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     bf16x8 a[RB][KS];
     {
         const uint64_t prow0 = (uint64_t)blockIdx.x * UNIT + (uint64_t)wave * (RB * 32);
+        set_lrow(prow0);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) load_features(a, prow0, ks);
     }
@@ -252,6 +270,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
         const uint64_t prow0 = unit * UNIT + (uint64_t)wave * (RB * 32);
         const uint64_t next_unit = unit + gridDim.x;
         const bool last_unit = next_unit >= n_units;
+        set_lrow((last_unit ? unit : next_unit) * UNIT + (uint64_t)wave * (RB * 32)); // long before the last G visit reads them
         float ssq[RB][16];
         f32x16 accA[RB], accB[RB]; // ping-pong accumulators of the column tiles; the finished one is squared into ssq
 #pragma unroll

@@ -371,14 +371,14 @@ int leann_internal_topk_chunk(const float *S, size_t rows, size_t nq, uint32_t k
     return LEANN_OK;
 }
 // reduction rounds until one segment per query remains, then keys -> (position + key_offset, score)
-static int scan_finish_ex(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k, uint64_t key_offset,
+int leann_internal_scan_finish_ex(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k, uint64_t key_offset,
                           uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st, const uint32_t *idx, int as_dist);
 int leann_internal_scan_finish(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k,
                                uint64_t key_offset, uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st) {
-    return scan_finish_ex(candA, candB, cand_len, total_segs, nq, k, key_offset, d_keys, d_scores, d_counts, st, nullptr, 0);
+    return leann_internal_scan_finish_ex(candA, candB, cand_len, total_segs, nq, k, key_offset, d_keys, d_scores, d_counts, st, nullptr, 0);
 }
 // idx: keys are indices into a row list (score_mfma_kernel<true>); as_dist: report 1 - score, the backends' distance
-static int scan_finish_ex(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k, uint64_t key_offset,
+int leann_internal_scan_finish_ex(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k, uint64_t key_offset,
                           uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st, const uint32_t *idx, int as_dist) {
     size_t m = total_segs * k;
     uint64_t *src = candA, *dst = candB;
@@ -480,8 +480,8 @@ static int scan_topk_impl(const float *d_rows, size_t n, size_t dims, size_t ld,
             seg_off += segs;
         }
         if (rc == LEANN_OK) {
-            if (emit) rc = scan_finish_ex(best, candB, k, 1, nq, k, key_offset, d_keys, d_scores, d_counts, st, idx, as_dist); // best = exact running top-k
-            else rc = scan_finish_ex(candA, candB, cand_len, total_segs, nq, k, key_offset, d_keys, d_scores, d_counts, st, idx, as_dist);
+            if (emit) rc = leann_internal_scan_finish_ex(best, candB, k, 1, nq, k, key_offset, d_keys, d_scores, d_counts, st, idx, as_dist); // best = exact running top-k
+            else rc = leann_internal_scan_finish_ex(candA, candB, cand_len, total_segs, nq, k, key_offset, d_keys, d_scores, d_counts, st, idx, as_dist);
         }
         // scratch is plain hipMalloc memory: wait for the stream before giving it back (this entry point
         // is synchronous; the stream-ordered allocator proved unreliable on this stack)
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256) allow_scatter_kernel(const uint8_t *__res
     }
 }
 // bitmap over n positions -> *d_list (hipMalloc'ed here, ascending positions), *n_list; synchronises the stream once for the count
-static int compact_allow(const uint8_t *d_allow, size_t n, uint32_t **d_list, size_t *n_list, hipStream_t st) {
+int leann_internal_compact_allow(const uint8_t *d_allow, size_t n, uint32_t **d_list, size_t *n_list, hipStream_t st) {
     const uint32_t nb = (uint32_t)((n + 8191) / 8192);
     uint32_t *blk = nullptr, total = 0;
     *d_list = nullptr;
@@ -611,7 +611,7 @@ int leann_internal_filtered_exact(const float *d_rows, size_t n, size_t dims, si
     for (size_t g = 0; g < groups; g++) {
         uint32_t *list = nullptr;
         size_t m = 0;
-        int rc = compact_allow(d_allow + g * allow_stride, n, &list, &m, st);
+        int rc = leann_internal_compact_allow(d_allow + g * allow_stride, n, &list, &m, st);
         if (rc != LEANN_OK) return rc;
         uint64_t *ok = d_keys + g * per * top_k;
         float *od = d_dists + g * per * top_k;

@@ -234,6 +234,27 @@ def test_multi_chunk_candidate_emission(la, po, gpu, monkeypatch):
     monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")
     nk, ns, nc = _search(la, r, dQ, nq, k, dM)
     assert (mk == nk).all() and (ms.view(np.uint32) == ns.view(np.uint32)).all()
+    monkeypatch.delenv("LEANN_DEBUG_NO_EMIT")
+    # The early filter (recompute.rs:62-79): a mask that allows at most half of the passages is compacted and only the allowed rows
+    # are embedded (fused_fstat_kernel<16, false, true>).  Per-passage arithmetic is unchanged, so the answer equals the masked
+    # pass over everything (LEANN_RECOMPUTE_NO_LIST=1) bit for bit — 20 % (emission over a 140k-row list), 0.3 % (slab only),
+    # 60 % (stays on the masked pass), an empty mask and a mask with fewer allowed rows than k.
+    rng = np.random.default_rng(11)
+    for sel in (0.2, 0.003, 0.6, 0.0, 5e-6):
+        allowed = rng.random(n) < sel
+        if sel == 5e-6:
+            allowed[:] = False
+            allowed[[7, 123456, 699999]] = True
+        mask = np.packbits(allowed, bitorder="little")
+        dM = la.DeviceArray.from_host(mask)
+        lk, ls, lc = _search(la, r, dQ, nq, k, dM)
+        monkeypatch.setenv("LEANN_RECOMPUTE_NO_LIST", "1")
+        fk, fs, fc = _search(la, r, dQ, nq, k, dM)
+        monkeypatch.delenv("LEANN_RECOMPUTE_NO_LIST")
+        assert (lc == fc).all() and (lk == fk).all() and (ls.view(np.uint32) == fs.view(np.uint32)).all(), sel
+        assert (lc == min(k, int(allowed.sum()))).all()
+        live = lk != np.iinfo(np.uint64).max
+        assert allowed[(lk[live] - 5000).astype(np.int64)].all()
     L.leann_recompute_close(r)
 
 
