@@ -67,23 +67,23 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
 #define FSTAT_W_HEAD_NR "s_waitcnt lgkmcnt(%[cnt])\n\t"
 #define FSTAT_SQ(q, p) "v_fma_f32 %[" #q "], %[" #p "], %[" #p "], %[" #q "]\n\t"
 #define FSTAT_W_RDZ(C0_, C1_, A0_, A1_, B_, NB_, ADDR_, OFF_, CNT_)                                                                    \
-    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[f0], %[bb], 0\n\t" FSTAT_MM "%[x1], %[f1], %[bb], 0"                       \
+    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[bb], %[f0], 0\n\t" FSTAT_MM "%[x1], %[bb], %[f1], 0"                       \
                  : [x0] "=&v"(C0_), [x1] "=&v"(C1_), [bb] "+v"(B_), [nb] "=&v"(NB_)                                                \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_) : "memory")
 #define FSTAT_W_RD(C0_, C1_, A0_, A1_, B_, NB_, ADDR_, OFF_, CNT_)                                                                     \
-    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_MM "%[x1], %[f1], %[bb], %[x1]"               \
+    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[bb], %[f0], %[x0]\n\t" FSTAT_MM "%[x1], %[bb], %[f1], %[x1]"               \
                  : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [nb] "=&v"(NB_)                                                  \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_) : "memory")
 #define FSTAT_W_RD_SQ1(C0_, C1_, A0_, A1_, B_, NB_, ADDR_, OFF_, CNT_, Q0_, P0_, Q1_, P1_)                                                 \
-    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_MM "%[x1], %[f1], %[bb], %[x1]\n\t" FSTAT_SQ(q1, p1) \
+    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[bb], %[f0], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_MM "%[x1], %[bb], %[f1], %[x1]\n\t" FSTAT_SQ(q1, p1) \
                  : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [nb] "=&v"(NB_), [q0] "+v"(Q0_), [q1] "+v"(Q1_)                     \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_), [p0] "v"(P0_), [p1] "v"(P1_) : "memory")
 #define FSTAT_W_NR_SQ1(C0_, C1_, A0_, A1_, B_, CNT_, Q0_, P0_, Q1_, P1_)                                                                \
-    asm volatile(FSTAT_W_HEAD_NR FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_MM "%[x1], %[f1], %[bb], %[x1]\n\t" FSTAT_SQ(q1, p1) \
+    asm volatile(FSTAT_W_HEAD_NR FSTAT_MM "%[x0], %[bb], %[f0], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_MM "%[x1], %[bb], %[f1], %[x1]\n\t" FSTAT_SQ(q1, p1) \
                  : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [q0] "+v"(Q0_), [q1] "+v"(Q1_)                                     \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [cnt] "i"(CNT_), [p0] "v"(P0_), [p1] "v"(P1_) : "memory")
-#define FSTAT_W_SQ3_BODY FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_SQ(q2, p2) FSTAT_SQ(q4, p4)         \
-                         FSTAT_MM "%[x1], %[f1], %[bb], %[x1]\n\t" FSTAT_SQ(q1, p1) FSTAT_SQ(q3, p3) FSTAT_SQ(q5, p5)
+#define FSTAT_W_SQ3_BODY FSTAT_MM "%[x0], %[bb], %[f0], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_SQ(q2, p2) FSTAT_SQ(q4, p4)         \
+                         FSTAT_MM "%[x1], %[bb], %[f1], %[x1]\n\t" FSTAT_SQ(q1, p1) FSTAT_SQ(q3, p3) FSTAT_SQ(q5, p5)
 #define FSTAT_W_RD_SQ3(C0_, C1_, A0_, A1_, B_, NB_, ADDR_, OFF_, CNT_, Q0_, P0_, Q1_, P1_, Q2_, P2_, Q3_, P3_, Q4_, P4_, Q5_, P5_)                 \
     asm volatile(FSTAT_W_HEAD_RD FSTAT_W_SQ3_BODY                                                                            \
                  : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [nb] "=&v"(NB_), [q0] "+v"(Q0_), [q1] "+v"(Q1_), [q2] "+v"(Q2_),     \
@@ -102,19 +102,19 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
 // the 64 pieces of a sub-slice cost ~1 000 cycles (the CU's 64 B/clk vector-memory path).
 #define FSTAT_DMA "s_mov_b32 m0, %[ld]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:%[doff]\n\t"
 #define FSTAT_W_RD_D(C0_, C1_, A0_, A1_, B_, NB_, ADDR_, OFF_, CNT_, VO_, SB_, LD_, DOFF_)                                    \
-    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_DMA FSTAT_MM "%[x1], %[f1], %[bb], %[x1]"    \
+    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[bb], %[f0], %[x0]\n\t" FSTAT_DMA FSTAT_MM "%[x1], %[bb], %[f1], %[x1]"    \
                  : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [nb] "=&v"(NB_)                                              \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_), [vo] "v"(VO_), [sb] "s"(SB_), \
                    [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
 #define FSTAT_W_RD_SQ1_D(C0_, C1_, A0_, A1_, B_, NB_, ADDR_, OFF_, CNT_, Q0_, P0_, Q1_, P1_, VO_, SB_, LD_, DOFF_)            \
-    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_DMA                        \
-                 FSTAT_MM "%[x1], %[f1], %[bb], %[x1]\n\t" FSTAT_SQ(q1, p1)                                                  \
+    asm volatile(FSTAT_W_HEAD_RD FSTAT_MM "%[x0], %[bb], %[f0], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_DMA                        \
+                 FSTAT_MM "%[x1], %[bb], %[f1], %[x1]\n\t" FSTAT_SQ(q1, p1)                                                  \
                  : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [nb] "=&v"(NB_), [q0] "+v"(Q0_), [q1] "+v"(Q1_)               \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [addr] "v"(ADDR_), [off] "i"(OFF_), [cnt] "i"(CNT_), [p0] "v"(P0_), [p1] "v"(P1_), \
                    [vo] "v"(VO_), [sb] "s"(SB_), [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
 #define FSTAT_W_NR_SQ1_D(C0_, C1_, A0_, A1_, B_, CNT_, Q0_, P0_, Q1_, P1_, VO_, SB_, LD_, DOFF_)                              \
-    asm volatile(FSTAT_W_HEAD_NR FSTAT_MM "%[x0], %[f0], %[bb], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_DMA                        \
-                 FSTAT_MM "%[x1], %[f1], %[bb], %[x1]\n\t" FSTAT_SQ(q1, p1)                                                  \
+    asm volatile(FSTAT_W_HEAD_NR FSTAT_MM "%[x0], %[bb], %[f0], %[x0]\n\t" FSTAT_SQ(q0, p0) FSTAT_DMA                        \
+                 FSTAT_MM "%[x1], %[bb], %[f1], %[x1]\n\t" FSTAT_SQ(q1, p1)                                                  \
                  : [x0] "+v"(C0_), [x1] "+v"(C1_), [bb] "+v"(B_), [q0] "+v"(Q0_), [q1] "+v"(Q1_)                                \
                  : [f0] "a"(A0_), [f1] "a"(A1_), [cnt] "i"(CNT_), [p0] "v"(P0_), [p1] "v"(P1_), [vo] "v"(VO_), [sb] "s"(SB_),  \
                    [ld] "s"(LD_), [doff] "i"(DOFF_) : "memory")
@@ -282,7 +282,13 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
         float inv[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) inv[rb] = 1.f;
-        for (int j = 0; j < nsub; j++, step++) {
+        // One sub-slice visit.  KIND (compile time): 0 = weight sub-slice, 1 = score sub-slice, 2 = the unit's LAST score sub-slice,
+        // whose loop also refills the feature fragments for the next unit.  The three kinds are separate instantiations called in
+        // sequence (not branches inside one visit loop): the refilled fragments are then redefined once, at the end of the unit
+        // body, and hipcc keeps them in their registers — as branches of one loop it gave the refilled values fresh registers, waited
+        // for the just-issued loads right behind the loop and moved 2 x 128 AGPRs per unit to restore the loop-carried assignment.
+        auto visit = [&](const int j, auto kind_c) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind_c)::value;
             const int buf = step & 1;
 #ifdef LEANN_STAMPS
             const uint64_t t0 = __builtin_amdgcn_s_memtime();
@@ -324,7 +330,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
 #ifdef LEANN_STAMPS
             const uint64_t tB = __builtin_amdgcn_s_memtime();
 #endif
-            if (j < nsw) {
+            if constexpr (KIND == 0) {
                 // 4 column tiles x KS k-steps, flat: fragment f+RING is requested while fragment f is multiplied.  The reads
                 // are asm statements (the compiler's scheduler otherwise sinks every read to just before its use, which with
                 // one wave per SIMD exposes the LDS latency 64 times per sub-slice); their lgkmcnt is counted by hand.
@@ -379,35 +385,22 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 stCW += tN - tB;
 #endif
                 if (j == nsw - 1) { // all columns seen: flush the last tile, then row norms (candle.rs:218-225)
-                    // sum over the 32 lanes of a half wave by DPP row shifts (__shfl_xor is an LDS permute: 160 of them cost
-                    // ~14 000 cycles per unit here); the totals land in lanes 31 and 63.  Step-major over the 16 values of a block:
-                    // independent chains, no hazard nop between a value's dependent DPP steps.
+                    // The encode tiles are computed transposed (A = weight fragment, B = feature fragment: D[i = column][j = passage]),
+                    // so a lane's 16 registers of every tile are 16 columns of ONE passage (j = lane & 31): the squares were summed
+                    // per register slot by the fillers, the row norm is those 16 partial sums plus the other half wave's (columns
+                    // i + 4) — one cross-lane exchange per block instead of a 5-step DPP tree over 32 values, and the result is
+                    // already per lane-passage, the layout the score epilogue wants.
 #pragma unroll
                     for (int rb = 0; rb < RB; rb++) {
                         float p[16];
 #pragma unroll
                         for (int reg = 0; reg < 16; reg++) p[reg] = fmaf(accB[rb][reg], accB[rb][reg], ssq[rb][reg]);
 #pragma unroll
-                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x111, 0xf); // row_shr:1
+                        for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
-                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x112, 0xf); // row_shr:2
-#pragma unroll
-                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x114, 0xf); // row_shr:4
-#pragma unroll
-                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x118, 0xf); // row_shr:8 -> lane 15 of each row of 16 = row total
-#pragma unroll
-                        for (int reg = 0; reg < 16; reg++) p[reg] = dpp_add(p[reg], 0x142, 0xa); // row_bcast:15 into rows 1 and 3
-                        if (l31 == 31) {
-#pragma unroll
-                            for (int reg = 0; reg < 16; reg++) sNrm[wave * (RB * 32) + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh] = p[reg];
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                    for (int rb = 0; rb < RB; rb++) { // from the C layout (rows in registers) to per-lane passages
-                        const float v = sqrtf(sNrm[wave * (RB * 32) + rb * 32 + l31]);
+                            for (int reg = 0; reg < w; reg++) p[reg] = p[reg] + p[reg + w];
+                        const float tot = p[0] + __shfl_xor(p[0], 32);
+                        const float v = sqrtf(tot);
                         inv[rb] = 1.0f / (v < 1e-12f ? 1e-12f : v);
                     }
                 }
@@ -447,8 +440,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                         if constexpr (PF) load_features(a, nprow0, ks);
                     });
                 };
-                if (qt == nqt - 1) g_loop(std::true_type{});
-                else g_loop(std::false_type{});
+                g_loop(std::integral_constant<bool, KIND == 2>{});
                 asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1])); // as above: no reader of the score tiles above the pad
 #ifdef LEANN_STAMPS
                 if (qt == 0) stGL += __builtin_amdgcn_s_memtime() - tB; else stGL1 += __builtin_amdgcn_s_memtime() - tB;
@@ -516,7 +508,11 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 else stWg += tW - t0;
             }
 #endif
-        }
+            step++;
+        };
+        for (int j = 0; j < nsw; j++) visit(j, std::integral_constant<int, 0>{});
+        for (int j = nsw; j < nsub - 1; j++) visit(j, std::integral_constant<int, 1>{});
+        visit(nsub - 1, std::integral_constant<int, 2>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pieces staged during the last visit: no DMA into LDS after the workgroup ends
 #ifdef LEANN_STAMPS
