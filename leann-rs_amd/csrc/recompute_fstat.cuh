@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     uint32_t step = 0; // sub-slices consumed so far: buffer = step & 1
     stage(0, 0);
 #ifdef LEANN_STAMPS
-    uint64_t stW = 0, stBar = 0, stIss = 0, stN = 0, stCW = 0, stCG = 0, stCN = 0, stGL = 0, stGL1 = 0, stWmid = 0, stW0 = 0, stW1 = 0, stWg = 0;
+    uint64_t stW = 0, stBar = 0, stIss = 0, stN = 0, stCW = 0, stCG = 0, stCN = 0, stGL = 0, stGL1 = 0; // (SGPR budget: no finer split)
 #endif
     f32x16 zero16;
 #pragma unroll
@@ -458,12 +458,16 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                     for (int rb = 0; rb < RB; rb++) {
                         const uint64_t row = prow0 + rb * 32 + l31;
                         float sv[16];
-                        bool any = false;
+                        // "does any score reach its threshold" as max(sv - th) >= 0: a - b >= 0 <=> a >= b in IEEE arithmetic (th = +-inf and
+                        // NaN scores included: fmaxf drops NaNs), and 8 v_pk_mul + 8 v_pk_add + 8 v_max3 instead of 16 compares whose
+                        // lane masks hipcc packed bit by bit through s_or / v_cndmask / shifts (~65 instructions per block)
+                        float m = __uint_as_float(0xFF800000u);
 #pragma unroll
                         for (int reg = 0; reg < 16; reg++) {
                             sv[reg] = sc[rb][reg] * inv[rb];
-                            any |= sv[reg] >= th[reg];
+                            m = fmaxf(m, sv[reg] - th[reg]);
                         }
+                        const bool any = m >= 0.0f;
                         if (any && row < n) {
                             const uint64_t pos = em.pos0 + row;
                             if (!em.allow || ((em.allow[pos >> 3] >> (pos & 7)) & 1)) {
@@ -502,10 +506,6 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 stW += tW - t0; stBar += tA - tW; stIss += tB - tA; stN += 1;
                 if (j >= nsw) stCG += tC - tB;
                 else if (j == nsw - 1) stCN += tC - tB; // whole last W visit (its loop is also in stCW): norm tail = stCN - stCW share
-                if (j >= 2 && j < nsw) stWmid += tW - t0;
-                else if (j == 0) stW0 += tW - t0;
-                else if (j == 1) stW1 += tW - t0;
-                else stWg += tW - t0;
             }
 #endif
             step++;
@@ -519,8 +519,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     if (tid == 0) {
         atomicAdd(&g_fstat_stamps[0], stW); atomicAdd(&g_fstat_stamps[1], stBar); atomicAdd(&g_fstat_stamps[2], stIss);
         atomicAdd(&g_fstat_stamps[4], stCW); atomicAdd(&g_fstat_stamps[5], stCG); atomicAdd(&g_fstat_stamps[6], stN);
-        atomicAdd(&g_fstat_stamps[8], stW0); atomicAdd(&g_fstat_stamps[9], stW1); atomicAdd(&g_fstat_stamps[10], stWmid);
-        atomicAdd(&g_fstat_stamps[11], stWg); atomicAdd(&g_fstat_stamps[12], stCN); atomicAdd(&g_fstat_stamps[13], stGL); atomicAdd(&g_fstat_stamps[14], stGL1);
+        atomicAdd(&g_fstat_stamps[12], stCN); atomicAdd(&g_fstat_stamps[13], stGL); atomicAdd(&g_fstat_stamps[14], stGL1);
     }
 #endif
 }

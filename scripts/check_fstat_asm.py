@@ -52,6 +52,50 @@ def scan_mfma_hazards(asm_text, min_mfmas=4):
     return bad
 
 
+def aregs(tok):
+    out = set()
+    for m in re.finditer(r'\ba\[(\d+):(\d+)\]|\ba(\d+)\b', tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def scan_async_loads(asm_text):
+    """The feature refill of the last score visit is an asm global_load into AGPRs; hipcc does not know the destination is in flight
+    until the next `s_waitcnt vmcnt(0)`.  Any instruction (MFMA or compiler-generated) that reads such an AGPR before that wait, and
+    any v_accvgpr shuffle in the kernel at all (the unit loop is written so that none is needed), is a violation."""
+    bad = []
+    for m in re.finditer(r'^(_Z\d+fused_fstat_kernel\w*):', asm_text, re.M):
+        body = asm_text[m.end():asm_text.index('s_endpgm', m.end())].split('\n')
+        flying, inasm = set(), False
+        for ln, l in enumerate(body):
+            t = l.strip()
+            if 'ASMSTART' in t:
+                inasm = True
+                continue
+            if 'ASMEND' in t:
+                inasm = False
+                continue
+            if not t or t[0] in ';.' or t.endswith(':'):
+                continue
+            if t.startswith('v_accvgpr'):
+                bad.append((m.group(1), ln, t))
+                continue
+            if t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
+                flying = set()
+                continue
+            ops = t.split(None, 1)[1] if ' ' in t else ''
+            if inasm and t.startswith('global_load_dwordx4 a'):
+                flying |= aregs(ops.split(',')[0])
+                continue
+            srcs = aregs(','.join(ops.split(',')[1:]))
+            if srcs & flying:
+                bad.append((m.group(1), ln, t))
+    return bad
+
+
 def scan(asm_text):
     bad, kernels = [], 0
     for m in re.finditer(r'^(_Z\d+fused_fstat_kernel\w*):', asm_text, re.M):
@@ -90,11 +134,13 @@ def main():
         text = open(out).read()
         kernels, bad = scan(text)
         haz = scan_mfma_hazards(text)
+        fly = scan_async_loads(text)
     print(f"{kernels} fused_fstat_kernel instantiations scanned, {len(bad)} early reads of in-flight asm ds_read destinations")
     print(f"{len(haz)} vector instructions reading an accumulator within 4 MFMAs of its last MFMA write")
-    for b in bad[:10] + haz[:10]:
+    print(f"{len(fly)} readers of an in-flight asm feature load / AGPR shuffles")
+    for b in bad[:10] + haz[:10] + fly[:10]:
         print("  ", b)
-    return 1 if bad or haz or kernels == 0 else 0
+    return 1 if bad or haz or fly or kernels == 0 else 0
 
 
 if __name__ == "__main__":

@@ -22,7 +22,7 @@ for it in range(2):
     chk(L.leann_recompute_search_batch_device(r, Q.data_ptr(), nq, k, None, keys.data_ptr(), sc.data_ptr(), cnt.data_ptr(), None)); torch.cuda.synchronize()
 out = (C.c_uint64 * 16)(); fn(out, 0)
 v = np.array(list(out), dtype=np.float64); tot = v[:6].sum()
-names = ["wait own DMA/stores/F", "barrier", "issue DMA", "", "compute W", "compute G + stores", "", "", "  wait at j=0 (after qt1 stores + F prefetch)", "  wait at j=1", "  wait at j=2..nsw-1", "  wait at G sub-slices", "  last W visit incl. norms (its MFMA loop is also counted in compute W)", "  G MFMA loop qt=0 (part of compute G)", "  G MFMA loop qt=1 with feature prefetch", ""]
+names = ["wait own DMA/stores/F", "barrier", "issue DMA", "", "compute W", "compute G + stores", "", "", "", "", "", "", "  last W visit incl. norms (its MFMA loop is also counted in compute W)", "  G MFMA loop, plain (part of compute G)", "  G MFMA loop of the last score visit, with feature prefetch", ""]
 ms3 = (C.c_float * 3)(); L.leann_recompute_last_timing(r, ms3)
 print(f"n={n}: fused {ms3[0]:.2f} ms, topk {ms3[2]:.2f} ms; sub-slice visits (wave 0 of each WG): {int(v[6])}")
 for nm, x in zip(names, v):

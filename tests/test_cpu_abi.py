@@ -84,6 +84,7 @@ def test_fused_kernel_asm_reads_are_not_consumed_early():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "3 fused_fstat_kernel instantiations scanned, 0 early reads" in r.stdout
     assert "0 vector instructions reading an accumulator within 4 MFMAs" in r.stdout  # MFMA -> VALU hazard distance (no hardware interlock)
+    assert "0 readers of an in-flight asm feature load / AGPR shuffles" in r.stdout   # no v_accvgpr moves around the unit loop
 
 
 def test_new_entry_points_reject_bad_arguments_without_a_gpu(la):
