@@ -58,17 +58,23 @@ __host__ __device__ __forceinline__ uint32_t node_level(uint64_t seed, uint64_t 
 // ---------------------------------------------------------------------------------------------
 // Canonical ("wave order") dot product — DESIGN.md §3, oracle/oracle.c:orc_dot_canon.
 // Lane l owns the 4 strided accumulators a[4l..4l+3]; chunk t covers elements 256t .. 256t+255.
-// After the fmaf chains: (a0+a1)+(a2+a3) in-lane, then an xor butterfly over masks 1,2,4,8,16,32
-// — the perfect adjacent-pair tree over the 256 accumulators.  Every lane ends with the total.
+// After the fmaf chains: (a0+a1)+(a2+a3) in-lane, then the perfect adjacent-pair tree over the 64 lane sums (levels 1, 2, 4, 8, 16,
+// 32) — the same pairs, hence the same bits, as an xor butterfly, but on the DPP path of the VALU: quad permutes for levels 1 and 2,
+// row shifts for 4 and 8 (the pair sum lands in the upper lane of each pair), row_bcast15 / row_bcast31 across rows; lane 63 ends
+// with the total, which v_readlane broadcasts.  (__shfl_xor compiles to ds_bpermute: six dependent LDS round trips per row batch.)
 // ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_pair_add(float v) { // lanes without a source, or outside ROW_MASK, add 0
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
 __device__ __forceinline__ float wave_tree_sum(float s) {
-    s = s + __shfl_xor(s, 1, 64);
-    s = s + __shfl_xor(s, 2, 64);
-    s = s + __shfl_xor(s, 4, 64);
-    s = s + __shfl_xor(s, 8, 64);
-    s = s + __shfl_xor(s, 16, 64);
-    s = s + __shfl_xor(s, 32, 64);
-    return s;
+    s = dpp_pair_add<0xB1, 0xf>(s);  // quad_perm [1,0,3,2]: lane ^ 1
+    s = dpp_pair_add<0x4E, 0xf>(s);  // quad_perm [2,3,0,1]: lane ^ 2
+    s = dpp_pair_add<0x114, 0xf>(s); // row_shr:4  -> lanes 4..7, 12..15 of each row hold the sums of 8
+    s = dpp_pair_add<0x118, 0xf>(s); // row_shr:8  -> lanes 12..15: the row's 16
+    s = dpp_pair_add<0x142, 0xa>(s); // row_bcast:15 into rows 1 and 3 -> lanes 28..31, 60..63: 32
+    s = dpp_pair_add<0x143, 0xc>(s); // row_bcast:31 into rows 2 and 3 -> lanes 60..63: all 64
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
 }
 __device__ __forceinline__ float lane4_sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
