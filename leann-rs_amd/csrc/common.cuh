@@ -76,6 +76,20 @@ __device__ __forceinline__ float wave_tree_sum(float s) {
     s = dpp_pair_add<0x143, 0xc>(s); // row_bcast:31 into rows 2 and 3 -> lanes 60..63: all 64
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
 }
+// minimum over the wave on the same DPP ladder (lanes without a source keep their own value); every lane gets the result
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_pair_min(uint32_t v) {
+    return min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_pair_min<0xB1, 0xf>(v);
+    v = dpp_pair_min<0x4E, 0xf>(v);
+    v = dpp_pair_min<0x114, 0xf>(v);
+    v = dpp_pair_min<0x118, 0xf>(v);
+    v = dpp_pair_min<0x142, 0xa>(v);
+    v = dpp_pair_min<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ float lane4_sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
 __device__ __forceinline__ void fma4(float4 &acc, const float4 &a, const float4 &b) {

@@ -402,12 +402,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     if (!(k & 1ull)) cand = rank;
                 }
                 // first unexpanded entry of the new list: wave-level min, one LDS atomic per wave
-                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 1, 64));
-                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 2, 64));
-                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 4, 64));
-                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 8, 64));
-                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 16, 64));
-                cand = min(cand, (uint32_t)__shfl_xor((int)cand, 32, 64));
+                cand = wave_min_u32(cand); // DPP ladder (common.cuh), not six ds_bpermute round trips
                 if (lane == 0 && cand != LEANN_EMPTY) atomicMin(next_slot, cand);
             }
             if (filt_level) {
