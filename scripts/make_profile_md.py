@@ -41,7 +41,7 @@ Files: `r01_hnsw10m_kernel_stats.csv` (all kernels of the process incl. index co
 | rocprofv3 kernel-trace average of the 20 timed dispatches (same run) | **{statistics.mean(d):.3f} ms** (min {min(d):.3f}, max {max(d):.3f}) |
 | bench.py HIP-event average (same profiled run) | **{b['roofline']['kernel_avg_ms']:.3f} ms** |
 | bench.py HIP-event average, un-profiled (`r01_hnsw10m_bench.json`) | {un['roofline']['kernel_avg_ms']:.3f} ms -> {un['value']:.0f} queries/s, recall@10 {un['recall_at_10']:.4f} |
-| launch geometry | 16 384 workgroups x 256 threads; compile-time 104 VGPR, 35 KB dynamic LDS, no scratch -> 4 workgroups per CU |
+| launch geometry | 16 384 workgroups x 256 threads; compile-time 99 VGPR, 35 KB dynamic LDS, no scratch -> 4 workgroups per CU (LDS) |
 | algorithmic bytes per launch (n_evals*768*4 + hops0*64*4 + hopsU*32*4, counted by the kernel) | {un['roofline']['algorithmic_bytes_per_launch']/1e9:.2f} GB ({un['roofline']['dist_evals_per_query']:.0f} distance evaluations + {un['roofline']['hops_per_query']:.0f} hops per query) |
 | achieved | {un['roofline']['achieved']:.0f} GB/s = **{un['roofline']['frac']*100:.1f} % of 8000 GB/s** |
 | PMC FETCH_SIZE per launch (raw / x2 gfx950 correction) | {fe/1e9:.2f} GB / {2*fe/1e9:.2f} GB |
@@ -56,10 +56,10 @@ efc=128, ef=128 (BASELINE configs[1] beam): 702 k queries/s, recall 0.979, 71.5 
 ## In-kernel stamps (diagnostic build `scripts/stamps.sh`, shares only): cycles per hop seen by wave 0, ef=64, 4M rows
 | phase | batch 64 (idle chip) | what |
 |---|---|---|
-| B | 2 300 (23 %) | adjacency list load + visited-table filter |
-| C | 3 800 (38 %) | row gather (one HBM round trip) + wave-tree reductions |
-| D | 2 100 (21 %) | merge by rank (was 7 700 before the 16-B pipelined scan) |
-| barriers | 1 700 (17 %) | three workgroup barriers |
+| B | 2 270 (26 %) | adjacency list load + visited-table filter |
+| C | 3 250 (36 %) | row gather (one HBM round trip) + wave-tree reductions (DPP ladder; 3 800 with ds_bpermute shuffles) |
+| D | 1 620 (18 %) | merge by rank (was 7 700 before the 16-B pipelined scan, 2 100 before the DPP wave minimum) |
+| barriers | 1 770 (20 %) | three workgroup barriers |
 
 ## Index construction (not in the timed region; {un['config']['index_build_s']:.0f} s for 10M x 768 at efc={b['config']['ef_construction']})
 `beam_search_kernel<3,4,4,true>` (construction searches) dominates; `select_kernel` and `reverse_merge_kernel` ~20 % each.
