@@ -123,19 +123,42 @@ __global__ void tile_weights_kernel(const uint16_t *__restrict__ W, uint32_t h, 
 // d-dimensional scoring GEMM against materialised embeddings becomes an h-dimensional one fused into
 // the encode loop, and the embeddings never leave the registers.
 // ------------------------------------------------------------------------------------------------
-__global__ void project_queries_kernel(const uint16_t *__restrict__ W, uint32_t h, uint32_t hp, uint32_t d,
-                                       const float *__restrict__ Q, uint32_t ldq, uint32_t nq, uint16_t *__restrict__ Gp,
-                                       int by_query_tile, uint32_t q_slots) {
+// Workgroup = 4 rows of W x 64 queries; the queries go through LDS in chunks of 64 columns (coalesced 256-B row pieces, stored
+// transposed so that consecutive queries sit in consecutive banks), the W values are wave-uniform.  Each g is still ONE fmaf chain,
+// j ascending — the arithmetic did not change, only the access pattern (one thread per (k, q) reading its query row straight from
+// global memory touched 64 cache lines per load instruction: 112 us per 64 queries, 0.45 ms per 256).
+__global__ void __launch_bounds__(256) project_queries_kernel(const uint16_t *__restrict__ W, uint32_t h, uint32_t hp, uint32_t d,
+                                                              const float *__restrict__ Q, uint32_t ldq, uint32_t nq,
+                                                              uint16_t *__restrict__ Gp, int by_query_tile, uint32_t q_slots) {
     // q_slots: query slots of the image (64 for encode_kernel; a multiple of 32 up to FSTAT_MAX_QUERIES for fused_fstat_kernel)
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; // (k, q)
-    if (idx >= hp * q_slots) return;
-    const uint32_t k = idx / q_slots, q = idx % q_slots;
+    __shared__ float sQ[64][65];
+    __shared__ float sW[4][64];
+    const uint32_t tid = threadIdx.x, kl = tid >> 6, ql = tid & 63;
+    const uint32_t k = blockIdx.x * 4 + kl, q = blockIdx.y * 64 + ql;
     float g = 0.f;
-    if (k < h && q < nq) {
-        const uint16_t *wk = W + (size_t)k * d;
-        const float *qv = Q + (size_t)q * ldq;
-        for (uint32_t j = 0; j < d; j++) g = fmaf(__uint_as_float((uint32_t)wk[j] << 16), qv[j], g);
+    for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; p++) { // 16 query rows per pass, 4 consecutive columns per thread
+            const uint32_t qr = (tid >> 4) + 16 * p, jj = (tid & 15) * 4, qg = blockIdx.y * 64 + qr;
+#pragma unroll
+            for (int e = 0; e < 4; e++) sQ[jj + e][qr] = (qg < nq && j0 + jj + e < d) ? Q[(size_t)qg * ldq + j0 + jj + e] : 0.f;
+        }
+        {
+            const uint32_t kr = blockIdx.x * 4 + (tid >> 6), jc = j0 + (tid & 63);
+            sW[tid >> 6][tid & 63] = (kr < h && jc < d) ? __uint_as_float((uint32_t)W[(size_t)kr * d + jc] << 16) : 0.f;
+        }
+        __syncthreads();
+        const uint32_t lim = min(64u, d - j0);
+        if (lim == 64) {
+#pragma unroll 16
+            for (uint32_t j = 0; j < 64; j++) g = fmaf(sW[kl][j], sQ[j][ql], g);
+        } else {
+            for (uint32_t j = 0; j < lim; j++) g = fmaf(sW[kl][j], sQ[j][ql], g);
+        }
     }
+    if (k >= hp || q >= q_slots) return;
+    if (!(k < h && q < nq)) g = 0.f;
     const uint16_t hi = f32_to_bf16_rne(g);
     const float r1 = g - __uint_as_float((uint32_t)hi << 16);
     const uint16_t lo = f32_to_bf16_rne(r1);
@@ -768,7 +791,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     for (size_t q0 = 0; q0 < nq && rc == LEANN_OK; q0 += QT) {
         const uint32_t nqt = (uint32_t)std::min<size_t>(QT, nq - q0);
         const uint32_t q_slots = use_fstat(r) ? (nqt + 31) / 32 * 32 : 64; // fused_fstat_kernel sizes its G image by 32-query tiles
-        hipLaunchKernelGGL(project_queries_kernel, dim3((unsigned)((r->hp * q_slots + 255) / 256)), dim3(256), 0, st, r->Wraw, (uint32_t)r->h,
+        hipLaunchKernelGGL(project_queries_kernel, dim3((unsigned)((r->hp + 3) / 4), (unsigned)((q_slots + 63) / 64)), dim3(256), 0, st, r->Wraw, (uint32_t)r->h,
                            (uint32_t)r->hp, (uint32_t)r->d, d_queries + q0 * r->d, (uint32_t)r->d, nqt, Gp, use_fstat(r) ? 1 : 0, q_slots);
         size_t seg_off = 0;
         for (size_t c = 0; c < n_chunks && rc == LEANN_OK; c++) {
