@@ -12,35 +12,31 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// dpp_add(v, ctrl, row_mask): v + (v shifted across lanes by a DPP control); lanes without a source, or outside row_mask, add 0
 // compile-time loop: the body sees its index as an integral_constant (inline-asm "i" operands need true constants)
 template <class Fn, int... I>
 __device__ __forceinline__ void static_for_impl(Fn &&fn, std::integer_sequence<int, I...>) { (fn(std::integral_constant<int, I>{}), ...); }
 template <int N, class Fn>
 __device__ __forceinline__ void static_for(Fn &&fn) { static_for_impl(fn, std::make_integer_sequence<int, N>{}); }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add_t(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
-}
-#define dpp_add(v, ctrl, row_mask) dpp_add_t<ctrl, row_mask>(v)
 
 // ------------------------------------------------------------------------------------------------
 // fused_fstat_kernel<KS>: the fused search pass with the FEATURES stationary in registers (h = 16*KS <= 256, L = 1).
 // encode_kernel<.., true, false> re-reads every operand fragment from LDS for each MFMA group (88 KB of LDS reads per
 // k-step per CU) and re-streams all of W (+G) from L2 for every 128 passages.  Here:
 //   * persistent workgroup of 4 waves, ONE wave per SIMD (512 registers each); unit = 4 x RB x 32 passages;
-//   * a wave keeps the A fragments of its RB x 32 passages for the whole K in registers (RB x KS x 4 VGPRs), so one
-//     16-B LDS read (a weight fragment) feeds RB MFMAs;
+//   * a wave keeps the feature fragments of its RB x 32 passages for the whole K in registers (RB x KS x 4 AGPRs, the B operand:
+//     every tile is computed as D[column or query][passage]), so one 16-B LDS read (a weight / G fragment, the A operand) feeds RB MFMAs;
 //   * W / G stream through a double-buffered LDS image in sub-slices of 128 columns (KS x 4 KiB, LDS-DMA with scalar
 //     base + per-lane offset, swizzled on the source side), one barrier per sub-slice;
 //   * per unit: dp/128 W sub-slices (4 column tiles each: MFMAs into ping-pong accumulators; the squares of a finished
-//     tile are folded into per-lane sums of squares in the shadow of the next tile's MFMAs) -> row norms (cross-lane, once
-//     per unit) -> 2 G sub-slices (query tile x {hi, lo, lo2} accumulated into one score tile; A = G fragment, B = the
+//     tile are folded into per-lane sums of squares in the shadow of the next tile's MFMAs) -> row norms (a lane's registers are
+//     columns of one passage: in-lane sum + one cross-half exchange, once per unit) -> nqt G sub-slices (query tile x {hi, lo, lo2} accumulated into one score tile; A = G fragment, B = the
 //     resident feature fragment) -> S[q][passage] = acc * (1 / norm); the next unit's features are fetched during the
 //     last G piece, each register right after its last use;
 //   * the weight fragments run through a 4-deep register ring (explicit software pipeline: with one wave per SIMD nobody
-//     else hides the LDS latency), and __builtin_amdgcn_sched_group_barrier pins the read / MFMA / VALU interleave.
+//     else hides the LDS latency); the loops are inline asm, one statement per k-step (see the FSTAT_* macros);
+//   * weight visits, score visits and the unit's last score visit (which refills the features) are three instantiations of one
+//     visit lambda called in sequence, so that no loop-carried register shuffle surrounds the refill.
 // ------------------------------------------------------------------------------------------------
 #ifdef LEANN_STAMPS // diagnostic build (scripts/stamps.sh): cycles per phase summed over wave 0 of every workgroup
 __device__ unsigned long long g_fstat_stamps[16];
