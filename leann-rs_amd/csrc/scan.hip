@@ -445,6 +445,14 @@ static int scan_topk_impl(const float *d_rows, size_t n, size_t dims, size_t ld,
         uint64_t *candA = nullptr, *candB = nullptr, *best = nullptr;
         unsigned char *emb = nullptr; // [slots f32 thr | slots u32 cnt | u32 overflow | pad | slots x EMIT_CAP u64]
         const size_t em_hdr = (slots * 8 + 4 + 255) / 256 * 256;
+        struct Scratch { // every early return (a failed allocation, a launch error) gives the pass's scratch back
+            void **p[5];
+            hipStream_t st;
+            ~Scratch() {
+                (void)hipStreamSynchronize(st); // plain hipMalloc memory: nothing may still be running on it
+                for (void **q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
+            }
+        } scratch{{(void **)&S, (void **)&candA, (void **)&candB, (void **)&best, (void **)&emb}, st};
         HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * nq * slab_rows));
         HIP_CHECK_RET(hipMalloc((void **)&candA, sizeof(uint64_t) * nq * cand_len));
         HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
@@ -488,12 +496,7 @@ static int scan_topk_impl(const float *d_rows, size_t n, size_t dims, size_t ld,
         (void)hipStreamSynchronize(st);
         uint32_t ov = 0;
         if (emit && rc == LEANN_OK && hipMemcpy(&ov, d_overflow, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = LEANN_ERR_DEVICE;
-        (void)hipFree(S);
-        (void)hipFree(candA);
-        (void)hipFree(candB);
-        (void)hipFree(best);
-        (void)hipFree(emb);
-        if (rc != LEANN_OK || !emit || ov == 0) return rc;
+        if (rc != LEANN_OK || !emit || ov == 0) return rc; // (~Scratch frees)
     }
     return LEANN_OK;
 }
