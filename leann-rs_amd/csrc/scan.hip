@@ -196,13 +196,17 @@ __global__ void __launch_bounds__(256) fold_candidates_kernel(uint64_t *__restri
     }
     const uint64_t *src = list + (size_t)q * cap;
     if (m) {
+        // sort width: the smallest power of two that takes the running best-k and all survivors (a few dozen to a few hundred keys
+        // after the first chunks) — a 512-key sort has 45 compare-exchange rounds of 1 pair per thread, the full 2048 one 66 of 4
+        int wsort = 64;
+        while (wsort < (int)(k + m) && wsort < SEG) wsort <<= 1;
         for (int i = threadIdx.x; i < (int)k; i += blockDim.x) keys[i] = best[(size_t)q * k + i];
-        for (uint32_t base = 0; base < m; base += SEG - k) {
-            for (int i = threadIdx.x; i < SEG - (int)k; i += blockDim.x) {
+        for (uint32_t base = 0; base < m; base += wsort - k) {
+            for (int i = threadIdx.x; i < wsort - (int)k; i += blockDim.x) {
                 const uint32_t p = base + i;
                 keys[k + i] = p < m ? src[p] : ~0ull;
             }
-            bitonic_sort_lds(keys, SEG);
+            bitonic_sort_lds(keys, wsort);
         }
         for (int i = threadIdx.x; i < (int)k; i += blockDim.x) best[(size_t)q * k + i] = keys[i];
         __syncthreads();
@@ -345,14 +349,16 @@ __global__ void __launch_bounds__(256) update_best_kernel(const uint64_t *__rest
     const uint32_t q = blockIdx.x;
     const uint64_t *src = cand + (size_t)q * cand_stride_q + (size_t)seg_off * k;
     const uint32_t m = n_segs * k;
-    // running selection: fold the candidate list through the LDS sorter SEG - k keys at a time
+    // running selection: fold the candidate list through the LDS sorter, as narrow as the list allows (see fold_candidates_kernel)
+    int wsort = 64;
+    while (wsort < (int)(k + m) && wsort < SEG) wsort <<= 1;
     for (int i = threadIdx.x; i < (int)k; i += blockDim.x) keys[i] = best[(size_t)q * k + i];
-    for (uint32_t base = 0; base < m; base += SEG - k) {
-        for (int i = threadIdx.x; i < SEG - (int)k; i += blockDim.x) {
+    for (uint32_t base = 0; base < m; base += wsort - k) {
+        for (int i = threadIdx.x; i < wsort - (int)k; i += blockDim.x) {
             uint32_t p = base + i;
             keys[k + i] = p < m ? src[p] : ~0ull;
         }
-        bitonic_sort_lds(keys, SEG);
+        bitonic_sort_lds(keys, wsort);
     }
     for (int i = threadIdx.x; i < (int)k; i += blockDim.x) best[(size_t)q * k + i] = keys[i];
 }
