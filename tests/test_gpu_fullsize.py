@@ -85,3 +85,33 @@ def test_fullsize_oracle_parity_on_sample(full, po):
     gk, gd, gc, gst = _search(la, s, Q.ptr, n, K, 128)
     assert (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all() and (gc == oc).all()
     assert (gst[:, 0] == ost[:, 0]).all() and (gst[:, 1] == ost[:, 1]).all() and (gst[:, 2] == ost[:, 2]).all()
+
+
+def test_fullsize_exact_filter_equals_masked_scan(full):
+    """Exact filtered search at full size (allowed rows compacted into a list and gathered) against the masked exact scan over all
+    rows (leann_scan_topk_device with the same allow mask): different code paths, the same fmaf chains -> the same keys, and
+    distance == 1 - score bit for bit; every key allowed; the filtered walk never beats it."""
+    la, L, chk, X, Q, nq, s = full
+    rng = np.random.default_rng(3)
+    n_q = 256
+    for sel in (0.01, 0.0005):
+        allowed = rng.random(ROWS) < sel
+        bm = np.packbits(allowed, bitorder="little")
+        dB = la.DeviceArray.from_host(bm)
+        ek, ed, ec = la.DeviceArray((n_q, K), np.uint64), la.DeviceArray((n_q, K), np.float32), la.DeviceArray(n_q, np.uint32)
+        s.search_filtered_exact_batch_device(Q.ptr, n_q, K, dB.ptr, 0, ek.ptr, ed.ptr, ec.ptr)
+        mk, ms, mc = la.DeviceArray((n_q, K), np.uint64), la.DeviceArray((n_q, K), np.float32), la.DeviceArray(n_q, np.uint32)
+        chk(L.leann_scan_topk_device(X.ptr, ROWS, D, D, Q.ptr, n_q, K, dB.ptr, 0, mk.ptr, ms.ptr, mc.ptr, None))
+        la.sync()
+        ek, ed, ec, mk, ms, mc = ek.to_host(), ed.to_host(), ec.to_host(), mk.to_host(), ms.to_host(), mc.to_host()
+        assert (ec == K).all() and (mc == K).all()
+        assert (ek == mk).all()
+        assert (ed.view(np.uint32) == (np.float32(1.0) - ms).view(np.uint32)).all()
+        assert allowed[ek.astype(np.int64)].all()
+        wk, wd, wc = la.DeviceArray((n_q, K), np.uint64), la.DeviceArray((n_q, K), np.float32), la.DeviceArray(n_q, np.uint32)
+        s.search_filtered_batch_device(Q.ptr, n_q, K, 128, dB.ptr, 0, wk.ptr, wd.ptr, wc.ptr)
+        la.sync()
+        wd, wc = wd.to_host(), wc.to_host()
+        for i in range(n_q):  # the walk's j-th best allowed distance is never better than the exact j-th best
+            c = int(wc[i])
+            assert (wd[i, :c] >= ed[i, :c] - 1e-6).all()
