@@ -52,6 +52,32 @@ def _hip_merge(keys, dists, counts, k_out, descending, stream):
     return ok, od, oc
 
 
+def start_exchange(keys, dists, counts, world, group=None):
+    """The exchange of `exchange_topk`, started asynchronously: returns a handle for `finish_exchange`.  Over RCCL the all-gather
+    runs on the process group's own stream behind the work already queued on the current one, so a search queued between start and
+    finish overlaps it (the exchange is latency-bound: 12 B per entry)."""
+    import torch.distributed as dist
+    nq, k = keys.shape
+    pack = torch.empty((nq, k, 3), dtype=torch.int32, device=keys.device)
+    pack[..., 0:2] = keys.contiguous().view(torch.int32).view(nq, k, 2)
+    pack[..., 2] = dists.contiguous().view(torch.int32)
+    cnt = counts.contiguous()
+    gathered = torch.empty((world * nq, k, 3), dtype=torch.int32, device=keys.device)
+    cnt_all = torch.empty((world * nq,), dtype=torch.int32, device=keys.device)
+    works = (dist.all_gather_into_tensor(gathered, pack, group=group, async_op=True),
+             dist.all_gather_into_tensor(cnt_all, cnt, group=group, async_op=True))
+    return works, gathered, cnt_all, pack, cnt, (world, nq, k)
+
+
+def finish_exchange(handle):
+    works, gathered, cnt_all, _pack, _cnt, (world, nq, k) = handle
+    for w in works:
+        w.wait()  # RCCL: the current stream waits for the collective (the host does not block); gloo: blocks until done
+    g_keys = gathered[..., 0:2].contiguous().view(torch.int64).view(world, nq, k)
+    g_dists = gathered[..., 2].contiguous().view(torch.float32).view(world, nq, k)
+    return g_keys, g_dists, cnt_all.view(world, nq)
+
+
 def exchange_topk(keys, dists, counts, world, group=None):
     """all-gather of per-shard lists: [nq,k] x3 -> [world,nq,k] x2 + [world,nq].
     One packed int32 buffer {key lo, key hi, dist bits} per rank + the counts (8 B + 4 B per entry:
@@ -82,6 +108,28 @@ class ShardedSearcher:
 
     def len(self):
         return self.n_total
+
+    def search_batches(self, batches, top_k, complexity, descending=False):
+        """Pipelined form of search_batch over an iterable of query batches (each identical on every rank): the all-gather of
+        batch i is in flight while the local search of batch i + 1 runs; yields the same (keys, dists, counts) as search_batch,
+        in order, one batch behind."""
+        pending = None
+        for queries in batches:
+            stream = torch.cuda.current_stream(queries.device).cuda_stream if queries.is_cuda else 0
+            keys, dists, counts = self._local(queries, top_k, complexity, stream)
+            if pending is not None:
+                yield self._finish(pending, top_k, descending)
+            pending = (keys, dists, counts) if self.world == 1 else start_exchange(keys, dists, counts, self.world, self.group)
+            pending = (pending, stream)
+        if pending is not None:
+            yield self._finish(pending, top_k, descending)
+
+    def _finish(self, pending, top_k, descending):
+        handle, stream = pending
+        if self.world == 1:
+            return handle
+        g_keys, g_dists, g_counts = finish_exchange(handle)
+        return self._merge(g_keys, g_dists, g_counts, top_k, descending, stream)
 
     def search_batch(self, queries, top_k, complexity, descending=False):
         """queries: [nq, dims] tensor, identical on every rank.  Returns global (keys, dists, counts)."""

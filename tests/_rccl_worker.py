@@ -33,6 +33,17 @@ def main(out):
         gk, gd, gc = exchange_topk(keys, dists, counts, world)
         mk, md, mc = _hip_merge(gk, gd, gc, k, False, stream.cuda_stream)
     stream.synchronize()
+    # the asynchronous form used by ShardedSearcher.search_batches: start, queue another search behind it, finish
+    from leann_rs_amd.shard import start_exchange, finish_exchange
+    hnd = start_exchange(keys, dists, counts, world)
+    k2, d2, c2 = ss.search_batch(Q, k, ef)             # overlaps the all-gather on the process group's stream
+    ak, ad, ac = finish_exchange(hnd)
+    torch.cuda.synchronize()
+    assert torch.equal(ak[0], keys) and torch.equal(ad[0], dists) and torch.equal(ac[0], counts)
+    assert torch.equal(k2, keys) and torch.equal(d2, dists)
+    outs = list(ss.search_batches([Q[:16], Q[16:]], k, ef))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([o[0] for o in outs]), keys)
     dist.barrier()
     assert gk.shape == (world, nq, k) and gc.shape == (world, nq)
     np.savez(out, keys=keys.cpu().numpy(), dists=dists.cpu().numpy(), counts=counts.cpu().numpy(), gk=gk.cpu().numpy(),

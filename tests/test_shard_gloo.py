@@ -56,6 +56,12 @@ def _worker(rank, world, port, n_total, d, nq, k, ef, outdir):
     ss = ShardedSearcher(None, n_total, world, rank, local_search=local_search, merge=merge)
     assert (ss.lo, ss.hi) == (lo, hi) and ss.len() == n_total
     keys, dists, counts = ss.search_batch(torch.from_numpy(Q), k, ef)
+    # pipelined form: the exchange of batch i is in flight while batch i + 1 is searched locally — same answers, in order
+    parts = [torch.from_numpy(Q[:7]), torch.from_numpy(Q[7:8]), torch.from_numpy(Q[8:])]
+    out = list(ss.search_batches(parts, k, ef))
+    assert len(out) == 3
+    pk = torch.cat([o[0] for o in out]); pd = torch.cat([o[1] for o in out]); pc = torch.cat([o[2] for o in out])
+    assert torch.equal(pk, keys) and torch.equal(pd, dists) and torch.equal(pc, counts)
     np.savez(os.path.join(outdir, f"r{rank}.npz"), keys=keys.numpy().view(np.uint64), dists=dists.numpy(),
              counts=counts.numpy())
     dist.barrier()
