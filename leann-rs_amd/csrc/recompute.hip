@@ -675,6 +675,8 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
 int leann_internal_scan_finish_ex(uint64_t *candA, uint64_t *candB, size_t cand_len, size_t total_segs, size_t nq, uint32_t k, uint64_t key_offset,
                                   uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st, const uint32_t *idx, int as_dist);
 int leann_internal_compact_allow(const uint8_t *d_allow, size_t n, uint32_t **d_list, size_t *n_list, hipStream_t st);
+int leann_internal_scratch_acquire(void **out, size_t bytes);
+void leann_internal_scratch_release(void *p);
 extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, const float *d_queries, size_t nq, size_t top_k,
                                                    const uint8_t *d_allow_mask, uint64_t *d_keys, float *d_scores,
                                                    uint32_t *d_counts, void *stream) {
@@ -693,10 +695,10 @@ extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, con
         int rc = leann_internal_compact_allow(d_allow_mask, r->n, &list, &n_list, (hipStream_t)stream);
         if (rc != LEANN_OK) return rc;
         if (n_list > r->n / 2) { // barely selective: the masked pass reads the fragment-major feature copy and skips the gather
-            (void)hipFree(list);
+            leann_internal_scratch_release(list); // (compact_allow synchronised the stream)
             list = nullptr;
         } else if (!list) { // nothing allowed: an empty list still needs a non-null marker for the list path
-            HIP_CHECK_RET(hipMalloc((void **)&list, 4));
+            if (int e = leann_internal_scratch_acquire((void **)&list, 4)) return e;
         }
     }
     bool overflowed = false;
@@ -704,7 +706,10 @@ extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, con
     // a candidate list overflowed (adversarial score order, e.g. ascending): repeat on the score-slab path
     if (rc == LEANN_OK && overflowed)
         rc = recompute_search_impl(r, d_queries, nq, top_k, d_allow_mask, d_keys, d_scores, d_counts, stream, false, &overflowed, list, n_list);
-    if (list) (void)hipFree(list); // recompute_search_impl synchronises the stream before it returns
+    if (list) {
+        (void)hipStreamSynchronize((hipStream_t)stream); // (already idle unless an error cut the search short)
+        leann_internal_scratch_release(list);
+    }
     return rc;
 }
 static int recompute_search_impl(const leann_recompute *r, const float *d_queries, size_t nq, size_t top_k, const uint8_t *d_allow_mask,

@@ -22,6 +22,86 @@
 
 
 // ------------------------------------------------------------------------------------------------
+// Scratch of the synchronous entry points (exact scan, exact filtered search, allow-bitmap compaction).  hipMalloc + hipFree cost
+// 20-50 us each and hipFree synchronises the device: ten of them per call were the 0.27 ms floor of a single-query exact filtered
+// search.  Blocks of at most 64 MiB are therefore kept in a small process-wide free list (at most 512 MiB, best fit per device) and
+// handed out again; larger blocks are allocated and freed per call.  A block is only released after the stream that used it has
+// been synchronised, so the next user — on any stream or thread — finds it idle.
+// ------------------------------------------------------------------------------------------------
+#include <unordered_map>
+namespace {
+struct PoolBlock { void *p; size_t cap; int dev; };
+std::mutex g_scratch_mu;
+std::vector<PoolBlock> g_scratch_free;
+std::unordered_map<void *, PoolBlock> g_scratch_out;
+size_t g_scratch_free_bytes = 0;
+constexpr size_t SCRATCH_BLOCK_MAX = (size_t)64 << 20, SCRATCH_TOTAL_MAX = (size_t)512 << 20;
+} // namespace
+int leann_internal_scratch_acquire(void **out, size_t bytes) {
+    *out = nullptr;
+    int dev = 0;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        size_t best = g_scratch_free.size();
+        for (size_t i = 0; i < g_scratch_free.size(); i++) {
+            const PoolBlock &b = g_scratch_free[i];
+            if (b.dev == dev && b.cap >= bytes && b.cap <= 4 * bytes + 65536 && (best == g_scratch_free.size() || b.cap < g_scratch_free[best].cap)) best = i;
+        }
+        if (best < g_scratch_free.size()) {
+            PoolBlock b = g_scratch_free[best];
+            g_scratch_free.erase(g_scratch_free.begin() + (long)best);
+            g_scratch_free_bytes -= b.cap;
+            g_scratch_out[b.p] = b;
+            *out = b.p;
+            return LEANN_OK;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { // give the cached blocks back and try once more
+        std::vector<PoolBlock> drop;
+        {
+            std::lock_guard<std::mutex> lk(g_scratch_mu);
+            drop.swap(g_scratch_free);
+            g_scratch_free_bytes = 0;
+        }
+        for (auto &b : drop) (void)hipFree(b.p);
+        (void)hipGetLastError();
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        leann_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return LEANN_ERR_DEVICE;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch_out[p] = PoolBlock{p, bytes, dev};
+    *out = p;
+    return LEANN_OK;
+}
+// the caller has synchronised every stream that touched the block
+void leann_internal_scratch_release(void *p) {
+    if (!p) return;
+    PoolBlock b{p, 0, 0};
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        auto it = g_scratch_out.find(p);
+        if (it != g_scratch_out.end()) {
+            b = it->second;
+            g_scratch_out.erase(it);
+            if (b.cap <= SCRATCH_BLOCK_MAX && g_scratch_free_bytes + b.cap <= SCRATCH_TOTAL_MAX) {
+                g_scratch_free.push_back(b);
+                g_scratch_free_bytes += b.cap;
+                keep = true;
+            }
+        }
+    }
+    if (!keep) (void)hipFree(p);
+}
+
+// ------------------------------------------------------------------------------------------------
 // score_mfma_kernel: S[q][i] for a tile of 128 rows x 64 queries on the f32 matrix cores.
 // v_mfma_f32_32x32x2_f32 computes D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) — a k-ordered f32 fmaf
 // chain, bit for bit (MI355X_MICROARCH.md §Matrix cores), so every score is the same single chain
@@ -455,20 +535,20 @@ static int scan_topk_impl(const float *d_rows, size_t n, size_t dims, size_t ld,
             void **p[5];
             hipStream_t st;
             ~Scratch() {
-                (void)hipStreamSynchronize(st); // plain hipMalloc memory: nothing may still be running on it
-                for (void **q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
+                (void)hipStreamSynchronize(st); // nothing may still be running on a block when it goes back to the pool
+                for (void **q : p) { leann_internal_scratch_release(*q); *q = nullptr; }
             }
         } scratch{{(void **)&S, (void **)&candA, (void **)&candB, (void **)&best, (void **)&emb}, st};
-        HIP_CHECK_RET(hipMalloc((void **)&S, sizeof(float) * nq * slab_rows));
-        HIP_CHECK_RET(hipMalloc((void **)&candA, sizeof(uint64_t) * nq * cand_len));
-        HIP_CHECK_RET(hipMalloc((void **)&candB, sizeof(uint64_t) * nq * cand_len));
-        HIP_CHECK_RET(hipMalloc((void **)&best, sizeof(uint64_t) * nq * k));
+        if (int e = leann_internal_scratch_acquire((void **)&S, sizeof(float) * nq * slab_rows)) return e;
+        if (int e = leann_internal_scratch_acquire((void **)&candA, sizeof(uint64_t) * nq * cand_len)) return e;
+        if (int e = leann_internal_scratch_acquire((void **)&candB, sizeof(uint64_t) * nq * cand_len)) return e;
+        if (int e = leann_internal_scratch_acquire((void **)&best, sizeof(uint64_t) * nq * k)) return e;
         HIP_CHECK_RET(hipMemsetAsync(candA, 0xFF, sizeof(uint64_t) * nq * cand_len, st));
         HIP_CHECK_RET(hipMemsetAsync(best, 0xFF, sizeof(uint64_t) * nq * k, st));
         CandEmit em{};
         uint32_t *d_overflow = nullptr;
         if (emit) {
-            HIP_CHECK_RET(hipMalloc((void **)&emb, em_hdr + sizeof(uint64_t) * slots * EMIT_CAP));
+            if (int e = leann_internal_scratch_acquire((void **)&emb, em_hdr + sizeof(uint64_t) * slots * EMIT_CAP)) return e;
             HIP_CHECK_RET(hipMemsetAsync(emb, 0, em_hdr, st));
             em.thr = reinterpret_cast<const float *>(emb);
             em.cnt = reinterpret_cast<uint32_t *>(emb + slots * 4);
@@ -575,26 +655,28 @@ __global__ void __launch_bounds__(256) allow_scatter_kernel(const uint8_t *__res
         v &= v - 1;
     }
 }
-// bitmap over n positions -> *d_list (hipMalloc'ed here, ascending positions), *n_list; synchronises the stream once for the count
+// bitmap over n positions -> *d_list (from the scratch pool: give it back with leann_internal_scratch_release once the stream that used
+// it is synchronised), ascending positions, *n_list; synchronises the stream once for the count
 int leann_internal_compact_allow(const uint8_t *d_allow, size_t n, uint32_t **d_list, size_t *n_list, hipStream_t st) {
     const uint32_t nb = (uint32_t)((n + 8191) / 8192);
     uint32_t *blk = nullptr, total = 0;
     *d_list = nullptr;
     *n_list = 0;
-    HIP_CHECK_RET(hipMalloc((void **)&blk, sizeof(uint32_t) * ((size_t)nb + 1)));
+    if (int e0 = leann_internal_scratch_acquire((void **)&blk, sizeof(uint32_t) * ((size_t)nb + 1))) return e0;
     hipLaunchKernelGGL(allow_count_kernel, dim3(nb), dim3(256), 0, st, d_allow, (uint64_t)n, blk);
     hipLaunchKernelGGL(allow_offsets_kernel, dim3(1), dim3(1024), 0, st, blk, nb);
     hipError_t e = hipMemcpyAsync(&total, blk + nb, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && total) e = hipMalloc((void **)d_list, sizeof(uint32_t) * (size_t)total);
+    if (e == hipSuccess && total && leann_internal_scratch_acquire((void **)d_list, sizeof(uint32_t) * (size_t)total) != LEANN_OK) e = hipErrorOutOfMemory;
     if (e == hipSuccess && total) {
         hipLaunchKernelGGL(allow_scatter_kernel, dim3(nb), dim3(256), 0, st, d_allow, (uint64_t)n, blk, *d_list);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st); // blk is freed below
+        if (e == hipSuccess) e = hipStreamSynchronize(st); // blk goes back to the pool below
     }
-    (void)hipFree(blk);
+    if (e != hipSuccess) (void)hipStreamSynchronize(st);
+    leann_internal_scratch_release(blk);
     if (e != hipSuccess) {
-        if (*d_list) (void)hipFree(*d_list);
+        leann_internal_scratch_release(*d_list);
         *d_list = nullptr;
         leann_set_error("HIP error: %s (compact_allow)", hipGetErrorString(e));
         return LEANN_ERR_DEVICE;
@@ -633,7 +715,7 @@ int leann_internal_filtered_exact(const float *d_rows, size_t n, size_t dims, si
         }
         rc = scan_topk_impl(d_rows, m, dims, ld, d_queries + g * per * dims, per, top_k, nullptr, key_offset, ok, od, oc, st, list, 1);
         (void)hipStreamSynchronize(st);
-        (void)hipFree(list);
+        leann_internal_scratch_release(list);
         if (rc != LEANN_OK) return rc;
     }
     return LEANN_OK;

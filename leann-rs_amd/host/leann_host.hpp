@@ -508,8 +508,8 @@ class IndexSearcher {
                 complexity = std::min<size_t>(1024, std::max<size_t>(complexity, (size_t)std::ceil(8.0 * (double)fetch_k / (20.0 * s_sel))));
             }
             // Selective filters (<= 5 % of the rows, or <= 64k rows) are answered exactly: the allowed rows are compacted and scanned on
-            // the device.  One query at a time (this call), 4M x 768 rows (scripts/filter_latency.py): 3 % allowed: 0.62 ms exact against
-            // 0.75 ms walking at recall 0.90; 1 %: 0.34 ms against 1.8 ms at 0.73; 10 %: 0.87 ms against 0.48 ms at 0.94 (the walk
+            // the device.  One query at a time (this call), 4M x 768 rows (scripts/filter_latency.py): 3 % allowed: 0.39 ms exact against
+            // 0.70 ms walking at recall 0.90; 1 %: 0.38 ms against 1.6 ms at 0.73; 10 %: 0.64 ms against 0.45 ms at 0.94 (the walk
             // wins from there).  In 16 384-query batches the crossover is ~1.5 %.  Indexes without stored vectors keep walking.
             bool done = false;
             if (allowed <= std::max<size_t>((size_t)(0.05 * (double)n_rows), 65536) && fetch_k <= 1024) {
