@@ -86,6 +86,21 @@ int leann_backend_search_filtered_exact_batch(const leann_backend *h, const floa
                                               size_t top_k, const uint8_t *allow, size_t allow_stride,
                                               uint64_t *keys, float *dists, uint32_t *counts);
 
+/* Additive: a filter registered on the device.  A server answers many queries under the same metadata filter; the calls above
+ * re-send the N/8-byte bitmap and (exact path) re-compact it for every query.  leann_backend_filter_create uploads the bitmap
+ * and builds the list of allowed positions once; leann_backend_search_filter_batch then answers nq queries under it.
+ * mode: 0 = walk the graph with the filter inside (leann_backend_search_filtered), 1 = exact scan of the allowed rows
+ * (leann_backend_search_filtered_exact_batch), 2 = choose: exact when the filter allows <= 5 % of the rows or <= 64k rows
+ * (batches of <= 64 queries) / <= 1.5 % (larger batches) and the index stores vectors, the walk otherwise.  Results are those of
+ * the corresponding call above, bit for bit.  Free the filter only when no search is using it. */
+typedef struct leann_filter leann_filter;
+int leann_backend_filter_create(const leann_backend *h, const uint8_t *allow, leann_filter **out);
+size_t leann_backend_filter_count(const leann_filter *f); /* allowed positions */
+void leann_backend_filter_free(leann_filter *f);
+int leann_backend_search_filter_batch(const leann_backend *h, const float *queries, size_t nq, size_t top_k,
+                                      size_t complexity, const leann_filter *filter, int mode,
+                                      uint64_t *keys, float *dists, uint32_t *counts);
+
 /* Additive: request coalescing for servers that call leann_backend_search from many threads (one query per
  * call, src/cli/serve.rs:289-292).  Concurrent callers are gathered for up to wait_us microseconds (or
  * max_batch queries) and answered by one batched launch; results are identical.  (0, 0) disables. */

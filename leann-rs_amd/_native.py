@@ -57,6 +57,10 @@ SIGNATURES = {
     "leann_backend_search_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, vp, vp,
                                                    vp, vp]),
     "leann_backend_search_filtered_exact_batch": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, u8p, C.c_size_t, u64p, f32p, u32p]),
+    "leann_backend_filter_create": (C.c_int, [vp, u8p, C.POINTER(vp)]),
+    "leann_backend_filter_count": (C.c_size_t, [vp]),
+    "leann_backend_filter_free": (None, [vp]),
+    "leann_backend_search_filter_batch": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_int, u64p, f32p, u32p]),
     "leann_backend_search_filtered_exact_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp]),
     "leann_backend_search_filtered_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t,
                                                             vp, vp, vp, vp, vp]),

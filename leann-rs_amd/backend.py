@@ -157,6 +157,29 @@ class BackendSearcher:
         N.check(N.lib().leann_backend_search_filtered_exact_batch_device(self._h, d_queries, nq, top_k, d_allow, allow_stride,
                                                                          d_keys, d_dists, d_counts, stream))
 
+    def register_filter(self, allow):
+        """upload + compact an allow-bitmap once; returns a Filter for search_filter_batch (close() it when done)"""
+        allow = np.ascontiguousarray(allow, np.uint8)
+        if allow.ndim != 1 or allow.shape[0] < (self.len() + 7) // 8:
+            raise LeannError(1, "allow-bitmap shape does not match the index")
+        h = C.c_void_p()
+        N.check(N.lib().leann_backend_filter_create(self._h, _p(allow, u8p), C.byref(h)))
+        return Filter(h)
+
+    def search_filter_batch(self, queries, top_k, complexity, flt, mode="auto"):
+        """nq queries under a registered filter; mode: "walk" | "exact" | "auto" (the library chooses by the filter's selectivity)"""
+        Q = np.ascontiguousarray(queries, np.float32)
+        if Q.ndim != 2 or Q.shape[1] != self.dims():
+            raise LeannError(1, f"queries must be [nq x {self.dims()}]")
+        nq = Q.shape[0]
+        keys = np.full((nq, top_k), np.iinfo(np.uint64).max, np.uint64)
+        dists = np.full((nq, top_k), np.inf, np.float32)
+        counts = np.zeros(nq, np.uint32)
+        N.check(N.lib().leann_backend_search_filter_batch(self._h, _p(Q, f32p), nq, top_k, complexity, flt._h,
+                                                          {"walk": 0, "exact": 1, "auto": 2}[mode], _p(keys, u64p), _p(dists, f32p),
+                                                          _p(counts, u32p)))
+        return keys, dists, counts
+
     def search_batch_device(self, d_queries, nq, top_k, complexity, d_keys, d_dists, d_counts,
                             d_stats=None, stream=None):
         N.check(N.lib().leann_backend_search_batch_device(self._h, d_queries, nq, top_k, complexity,
@@ -265,3 +288,25 @@ class BackendBuilder:
         X = np.ascontiguousarray(embeddings, np.float32)
         N.check(N.lib().leann_backend_add(int(self.backend_type), _p(X, f32p), X.shape[0], dimensions,
                                           start_id, os.fsencode(str(index_path))))
+
+
+
+class Filter:
+    """a metadata filter registered on the device (leann_backend_filter_create)"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def count(self):
+        return int(N.lib().leann_backend_filter_count(self._h))
+
+    def close(self):
+        if self._h:
+            N.lib().leann_backend_filter_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -315,12 +315,78 @@ extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *
 }
 
 // ... with an optional allow-bitmap over positions (host memory; one shared bitmap when allow_stride == 0)
+// A filter registered on the device (leann_backend_filter_create): the bitmap, the ascending list of allowed positions and its length.
+struct leann_filter {
+    int device = 0;
+    size_t n = 0, n_allowed = 0;
+    uint8_t *d_allow = nullptr;
+    uint32_t *d_list = nullptr; // scratch-pool block (scan.hip), held for the filter's lifetime
+};
+enum { FILTER_WALK = 0, FILTER_EXACT = 1, FILTER_AUTO = 2 };
 static int search_filtered_batch_host(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
-                                      const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, bool exact);
+                                      const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, int mode,
+                                      const leann_filter *flt = nullptr);
+int leann_internal_compact_allow(const uint8_t *d_allow, size_t n, uint32_t **d_list, size_t *n_list, hipStream_t st);
+void leann_internal_scratch_release(void *p);
+int leann_internal_filtered_exact_list(const float *d_rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t top_k,
+                                       const uint32_t *d_list, size_t m, uint64_t key_offset, uint64_t *d_keys, float *d_dists,
+                                       uint32_t *d_counts, hipStream_t st);
+
+// Registered filters: a server that answers many queries under the same metadata filter uploads and compacts the bitmap once
+// (the host-pointer calls above re-send N/8 bytes and re-compact them for every query: 1.25 MB at 10M rows).
+extern "C" int leann_backend_filter_create(const leann_backend *hc, const uint8_t *allow, leann_filter **out) {
+    if (!hc || !allow || !out) {
+        leann_set_error("leann_backend_filter_create: null argument");
+        return LEANN_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (hc->g.n >= (1ull << 32)) {
+        leann_set_error("leann_backend_filter_create: the index has 2^32 rows or more");
+        return LEANN_ERR_INVALID;
+    }
+    HIP_CHECK_RET(hipSetDevice(hc->device));
+    leann_filter *f = new leann_filter();
+    f->device = hc->device;
+    f->n = hc->g.n;
+    const size_t nbytes = std::max<size_t>((f->n + 7) / 8, 1);
+    if (hipMalloc((void **)&f->d_allow, nbytes) != hipSuccess || hipMemcpy(f->d_allow, allow, (f->n + 7) / 8, hipMemcpyHostToDevice) != hipSuccess) {
+        leann_set_error("leann_backend_filter_create: device allocation / copy of %zu bytes failed", nbytes);
+        if (f->d_allow) (void)hipFree(f->d_allow);
+        delete f;
+        return LEANN_ERR_DEVICE;
+    }
+    int rc = f->n ? leann_internal_compact_allow(f->d_allow, f->n, &f->d_list, &f->n_allowed, nullptr) : LEANN_OK;
+    if (rc != LEANN_OK) {
+        (void)hipFree(f->d_allow);
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return LEANN_OK;
+}
+extern "C" size_t leann_backend_filter_count(const leann_filter *f) { return f ? f->n_allowed : 0; }
+extern "C" void leann_backend_filter_free(leann_filter *f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize(); // searches on any stream may still be reading the bitmap / the list
+    leann_internal_scratch_release(f->d_list);
+    if (f->d_allow) (void)hipFree(f->d_allow);
+    delete f;
+}
+extern "C" int leann_backend_search_filter_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
+                                                 const leann_filter *filter, int mode, uint64_t *keys, float *dists, uint32_t *counts) {
+    if (!filter || !hc || filter->n != hc->g.n || filter->device != hc->device || mode < FILTER_WALK || mode > FILTER_AUTO) {
+        leann_set_error("leann_backend_search_filter_batch: null / foreign filter (made for %zu rows, the index has %zu) or bad mode %d",
+                        filter ? filter->n : (size_t)0, hc ? (size_t)hc->g.n : (size_t)0, mode);
+        return LEANN_ERR_INVALID;
+    }
+    return search_filtered_batch_host(hc, queries, nq, top_k, complexity, nullptr, 0, keys, dists, counts, mode, filter);
+}
+
 extern "C" int leann_backend_search_filtered_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k,
                                                    size_t complexity, const uint8_t *allow, size_t allow_stride,
                                                    uint64_t *keys, float *dists, uint32_t *counts) {
-    return search_filtered_batch_host(hc, queries, nq, top_k, complexity, allow, allow_stride, keys, dists, counts, false);
+    return search_filtered_batch_host(hc, queries, nq, top_k, complexity, allow, allow_stride, keys, dists, counts, FILTER_WALK);
 }
 // ... answered exactly: the allowed rows are compacted and scanned (scan.hip), no graph involved
 extern "C" int leann_backend_search_filtered_exact_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k,
@@ -330,7 +396,7 @@ extern "C" int leann_backend_search_filtered_exact_batch(const leann_backend *hc
         leann_set_error("leann_backend_search_filtered_exact_batch: null allow-bitmap");
         return LEANN_ERR_INVALID;
     }
-    return search_filtered_batch_host(hc, queries, nq, top_k, 0, allow, allow_stride, keys, dists, counts, true);
+    return search_filtered_batch_host(hc, queries, nq, top_k, 0, allow, allow_stride, keys, dists, counts, FILTER_EXACT);
 }
 int leann_internal_filtered_exact(const float *d_rows, size_t n, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t top_k,
                                   const uint8_t *d_allow, size_t allow_stride, uint64_t key_offset, uint64_t *d_keys, float *d_dists,
@@ -362,8 +428,16 @@ extern "C" int leann_backend_search_filtered_exact_batch_device(const leann_back
                                          d_dists, d_counts, st);
 }
 static int search_filtered_batch_host(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
-                                      const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, bool exact) {
+                                      const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, int mode,
+                                      const leann_filter *flt) {
     leann_backend *h = const_cast<leann_backend *>(hc);
+    // exact scan of the allowed rows, or the walk with the filter inside?  FILTER_AUTO (registered filters only: the count is known):
+    // exact up to 5 % of the rows / 64k rows for small batches, 1.5 % for large ones, when the index stores vectors
+    bool exact = mode == FILTER_EXACT;
+    if (mode == FILTER_AUTO && flt && hc && !hc->g.feat_h && top_k <= 1024) {
+        const double frac = nq <= 64 ? 0.05 : 0.015;
+        exact = flt->n_allowed <= std::max<size_t>((size_t)(frac * (double)hc->g.n), nq <= 64 ? 65536 : 0);
+    }
     if (!h || !queries || !keys || !dists || !counts) {
         leann_set_error("leann_backend_search_batch: null argument");
         return LEANN_ERR_INVALID;
@@ -435,9 +509,17 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
     a.out_dists = w->d_dists;
     a.out_counts = w->d_counts;
     a.out_stats = w->d_stats;
-    a.allow = allow ? w->d_allow : nullptr;
-    a.allow_stride = allow_stride;
-    if (exact) {
+    a.allow = flt ? flt->d_allow : (allow ? w->d_allow : nullptr);
+    a.allow_stride = flt ? 0 : allow_stride;
+    if (exact && flt) {
+        if (h->g.feat_h) {
+            leann_set_error("exact filtered search needs stored vectors; this index recomputes them from features");
+            return fail(LEANN_ERR_UNSUPPORTED);
+        }
+        if (hipMemsetAsync(w->d_stats, 0, nq * 16, st) != hipSuccess) return fail(LEANN_ERR_DEVICE);
+        rc = leann_internal_filtered_exact_list(h->g.X, h->g.d, h->g.ld, w->d_q, nq, top_k, flt->d_list, flt->n_allowed, h->key_offset,
+                                                w->d_keys, w->d_dists, w->d_counts, st);
+    } else if (exact) {
         if (h->g.feat_h) {
             leann_set_error("exact filtered search needs stored vectors; this index recomputes them from features");
             return fail(LEANN_ERR_UNSUPPORTED);

@@ -689,6 +689,22 @@ __global__ void fill_empty_results_kernel(uint64_t *__restrict__ keys, float *__
     if (i < nq * k) { keys[i] = ~0ull; dists[i] = __uint_as_float(0x7F800000u); }
     if (i < nq) counts[i] = 0;
 }
+// exact search over an already compacted list of m allowed positions (api.hip: registered filters)
+int leann_internal_filtered_exact_list(const float *d_rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t top_k,
+                                       const uint32_t *d_list, size_t m, uint64_t key_offset, uint64_t *d_keys, float *d_dists,
+                                       uint32_t *d_counts, hipStream_t st) {
+    if (top_k == 0 || top_k > SEG / 2) {
+        leann_set_error("exact filtered search: top_k must be in [1, %d] (top_k=%zu)", SEG / 2, top_k);
+        return LEANN_ERR_INVALID;
+    }
+    if (m == 0) {
+        const size_t cells = std::max(nq * top_k, nq);
+        hipLaunchKernelGGL(fill_empty_results_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_keys, d_dists, d_counts, nq, top_k);
+        HIP_CHECK_RET(hipGetLastError());
+        return LEANN_OK;
+    }
+    return scan_topk_impl(d_rows, m, dims, ld, d_queries, nq, top_k, nullptr, key_offset, d_keys, d_dists, d_counts, st, d_list, 1);
+}
 // api.hip: leann_backend_search_filtered_exact_batch_device.  Rows [n x dims] (leading dimension ld), one bitmap for the batch
 // (allow_stride == 0) or one per query.
 int leann_internal_filtered_exact(const float *d_rows, size_t n, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t top_k,

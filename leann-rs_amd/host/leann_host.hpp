@@ -496,32 +496,23 @@ class IndexSearcher {
         if (opts.filter && opts.device_filter) {
             // every returned position already passes the filter, so no over-fetch is needed for it
             if (!opts.hybrid) { fetch_k = opts.top_k; }
-            const std::vector<uint8_t> &bm = allow_bitmap(*opts.filter, opts.filter_key);
-            // The answer comes from the pool of evaluated nodes (20-33 x complexity for M = 16-32): widen the walk so that the pool is
+            // The filter lives on the device (bitmap + compacted list of allowed positions), registered once per distinct filter.
+            const RegisteredFilter rf = device_filter(*opts.filter, opts.filter_key);
+            // The walk answers from the pool of evaluated nodes (20-33 x complexity for M = 16-32): widen it so that the pool is
             // expected to hold >= 8 x fetch_k allowed passages (selectivity s: complexity >= 8 fetch_k / (20 s)), capped at 1024.
-            size_t allowed = 0;
-            for (uint8_t b : bm) allowed += (size_t)__builtin_popcount(b);
             size_t complexity = opts.complexity;
             const size_t n_rows = std::max<size_t>(leann_backend_len(backend_.get()), 1);
-            if (allowed > 0) {
-                const double s_sel = (double)allowed / (double)n_rows;
+            if (rf.allowed > 0) {
+                const double s_sel = (double)rf.allowed / (double)n_rows;
                 complexity = std::min<size_t>(1024, std::max<size_t>(complexity, (size_t)std::ceil(8.0 * (double)fetch_k / (20.0 * s_sel))));
             }
-            // Selective filters (<= 5 % of the rows, or <= 64k rows) are answered exactly: the allowed rows are compacted and scanned on
-            // the device.  One query at a time (this call), 4M x 768 rows (scripts/filter_latency.py): 3 % allowed: 0.39 ms exact against
-            // 0.70 ms walking at recall 0.90; 1 %: 0.38 ms against 1.6 ms at 0.73; 10 %: 0.64 ms against 0.45 ms at 0.94 (the walk
-            // wins from there).  In 16 384-query batches the crossover is ~1.5 %.  Indexes without stored vectors keep walking.
-            bool done = false;
-            if (allowed <= std::max<size_t>((size_t)(0.05 * (double)n_rows), 65536) && fetch_k <= 1024) {
-                uint32_t cnt = 0;
-                const int rc = leann_backend_search_filtered_exact_batch(backend_.get(), query_embedding.data(), 1, fetch_k, bm.data(), 0,
-                                                                         keys.data(), dists.data(), &cnt);
-                if (rc == LEANN_OK) { n = cnt; done = true; }
-                else if (rc != LEANN_ERR_UNSUPPORTED) check(rc);
-            }
-            if (!done)
-                check(leann_backend_search_filtered(backend_.get(), query_embedding.data(), fetch_k, complexity, bm.data(),
-                                                    keys.data(), dists.data(), &n));
+            // mode 2: the library answers selective filters (<= 5 % of the rows, or <= 64k rows) exactly — the allowed rows are scanned
+            // on the device — and walks otherwise.  One query at a time, 10M x 768 rows (scripts/filter_latency.py): 3 % allowed: 0.49 ms
+            // exact against 0.80 ms walking at recall 0.92; 1 %: 0.32 ms against 1.8 ms at 0.84; 10 %: 1.1 ms against 0.46 ms at 0.89.
+            uint32_t cnt = 0;
+            check(leann_backend_search_filter_batch(backend_.get(), query_embedding.data(), 1, fetch_k, complexity, rf.handle.get(), 2,
+                                                    keys.data(), dists.data(), &cnt));
+            n = cnt;
         } else {
             check(leann_backend_search(backend_.get(), query_embedding.data(), fetch_k, opts.complexity, keys.data(), dists.data(), &n));
         }
@@ -580,28 +571,38 @@ class IndexSearcher {
         if (!bm25_) bm25_ = std::make_shared<Bm25Scorer>(Bm25Scorer::build(get_all_texts()));
         return *bm25_;
     }
-    // one pass over the passage metadata per distinct filter (the index is immutable while open); bit i = position i
-    const std::vector<uint8_t> &allow_bitmap(const MetadataFilter &f, const std::string &key) const {
+    // one pass over the passage metadata per distinct filter (the index is immutable while open); bit i = position i.  The bitmap is
+    // registered on the device once (leann_backend_filter_create) and reused by every query under the same filter.
+    struct RegisteredFilter {
+        std::shared_ptr<leann_filter> handle;
+        size_t allowed = 0;
+    };
+    RegisteredFilter device_filter(const MetadataFilter &f, const std::string &key) const { // by value: keeps the handle alive past an eviction
         std::lock_guard<std::mutex> lk(*bm25_mu_);
         if (!key.empty()) {
-            auto it = bitmaps_->find(key);
-            if (it != bitmaps_->end()) return it->second;
+            auto it = filters_->find(key);
+            if (it != filters_->end()) return it->second;
         }
         const size_t n = leann_backend_len(backend_.get());
-        std::vector<uint8_t> bm((n + 7) / 8, 0);
+        std::vector<uint8_t> bm((n + 7) / 8 + 1, 0);
         for (size_t i = 0; i < n; i++) {
             std::string id = i < id_map_.size() ? id_map_[i] : std::to_string(i);
             try {
                 if (f.matches(passages_.get(id).metadata)) bm[i >> 3] |= (uint8_t)(1u << (i & 7));
             } catch (...) {} // unreadable passage: never returned (the post-filter path skips it with a warning too)
         }
-        if (bitmaps_->size() >= 16) bitmaps_->clear();
-        return (*bitmaps_)[key.empty() ? std::string("\x01anon") : key] = std::move(bm);
+        leann_filter *raw = nullptr;
+        check(leann_backend_filter_create(backend_.get(), bm.data(), &raw));
+        RegisteredFilter rf;
+        rf.handle = std::shared_ptr<leann_filter>(raw, [](leann_filter *p) { leann_backend_filter_free(p); });
+        rf.allowed = leann_backend_filter_count(raw);
+        if (filters_->size() >= 16) filters_->clear();
+        return (*filters_)[key.empty() ? std::string("\x01anon") : key] = std::move(rf);
     }
     PassageStore passages_;
     std::shared_ptr<leann_backend> backend_;
     std::vector<std::string> id_map_;
-    std::shared_ptr<std::map<std::string, std::vector<uint8_t>>> bitmaps_ = std::make_shared<std::map<std::string, std::vector<uint8_t>>>();
+    std::shared_ptr<std::map<std::string, RegisteredFilter>> filters_ = std::make_shared<std::map<std::string, RegisteredFilter>>();
     mutable std::shared_ptr<Bm25Scorer> bm25_;
     std::shared_ptr<std::mutex> bm25_mu_ = std::make_shared<std::mutex>();
 };

@@ -107,6 +107,14 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu(la):
     assert rc == 1 and b"null" in L.leann_last_error()
     rc = L.leann_backend_search_filtered_exact_batch_device(None, None, 1, 4, None, 0, None, None, None, None)
     assert rc == 1
+    flt = C.c_void_p()
+    rc = L.leann_backend_filter_create(None, bm.ctypes.data_as(u8p), C.byref(flt))
+    assert rc == 1 and b"null" in L.leann_last_error() and not flt.value
+    rc = L.leann_backend_search_filter_batch(None, q.ctypes.data_as(f32p), 1, 4, 16, None, 2, keys.ctypes.data_as(u64p),
+                                             dists.ctypes.data_as(f32p), cnt.ctypes.data_as(u32p))
+    assert rc == 1
+    assert L.leann_backend_filter_count(None) == 0
+    L.leann_backend_filter_free(None)
     rc = L.leann_recompute_search_batch(None, q.ctypes.data_as(f32p), 1, 4, None, keys.ctypes.data_as(u64p), dists.ctypes.data_as(f32p),
                                         cnt.ctypes.data_as(u32p))
     assert rc == 1 and b"null" in L.leann_last_error()

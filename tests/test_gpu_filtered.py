@@ -208,3 +208,44 @@ def test_filtered_exact_matches_oracle(la, po, gpu, n, d, nq):
     with pytest.raises(la.LeannError):
         s.search_filtered_exact_batch(Q, 5000, bm)
     s.close()
+
+
+def test_registered_filter_matches_the_per_call_paths(la, po, gpu):
+    """leann_backend_filter_create uploads + compacts a bitmap once; searching under it must equal the per-call entry points bit
+    for bit in both modes, and mode "auto" must pick the exact scan for selective filters and the walk for broad ones."""
+    n, d, nq, k, ef = 30000, 64, 40, 10, 48
+    rng = np.random.default_rng(9)
+    X = synth(po, n, d)
+    Q = synth(po, nq, d, stream=1)
+    dX = la.DeviceArray.from_host(X)
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, d, 8, 32, key_offset=77)
+    for sel, auto_is_exact in ((0.5, False), (0.01, True), (0.0, True)):
+        bm, allowed = _bitmap(rng, n, sel)
+        f = s.register_filter(bm)
+        assert f.count() == int(allowed.sum())
+        wk, wd, wc = s.search_filter_batch(Q, k, ef, f, "walk")
+        rk, rd, rc = s.search_filtered_batch(Q, k, ef, bm)
+        assert (wk == rk).all() and (wd.view(np.uint32) == rd.view(np.uint32)).all() and (wc == rc).all()
+        ek, ed, ec = s.search_filter_batch(Q, k, ef, f, "exact")
+        xk, xd, xc = s.search_filtered_exact_batch(Q, k, bm)
+        assert (ek == xk).all() and (ed.view(np.uint32) == xd.view(np.uint32)).all() and (ec == xc).all()
+        ak, ad, ac = s.search_filter_batch(Q, k, ef, f, "auto")
+        want = (ek, ed, ec) if auto_is_exact or allowed.sum() <= 65536 else (wk, wd, wc)
+        assert (ak == want[0]).all() and (ad.view(np.uint32) == want[1].view(np.uint32)).all() and (ac == want[2]).all()
+        # a large batch under a broad filter walks (<= 1.5 % rule), under a selective one still scans
+        Qb = np.repeat(Q, 3, axis=0)[:100]
+        bk, bd, bc = s.search_filter_batch(Qb, k, ef, f, "auto")
+        if sel == 0.5:
+            ck, cd, cc = s.search_filtered_batch(Qb, k, ef, bm)
+        else:
+            ck, cd, cc = s.search_filtered_exact_batch(Qb, k, bm)
+        assert (bk == ck).all() and (bd.view(np.uint32) == cd.view(np.uint32)).all() and (bc == cc).all()
+        f.close()
+    # a filter made for another index is refused
+    s2 = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n - 8, d, d, 8, 32)
+    f2 = s2.register_filter(np.zeros((n + 7) // 8, np.uint8))
+    with pytest.raises(la.LeannError):
+        s.search_filter_batch(Q, k, ef, f2, "auto")
+    f2.close()
+    s2.close()
+    s.close()
