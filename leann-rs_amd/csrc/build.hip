@@ -58,8 +58,9 @@ __device__ __forceinline__ void list_ptr(const ListView &lv, uint32_t node, uint
 // ------------------------------------------------------------------------------------------------
 template <int TS> // per-thread tile TS x TS; the 16 x 16 thread grid covers 16*TS candidates
 __device__ __forceinline__ void gram_lower(const float *__restrict__ X, uint32_t ld, const uint32_t *c_id, uint32_t nc,
-                                           float *tri, float *stage) {
-    constexpr int KC = 32, LDW = NCMAX + 1;
+                                           float *tri, float *stage_) {
+    float *stage = static_cast<float *>(__builtin_assume_aligned(stage_, 16));
+    constexpr int KC = 32, LDW = NCMAX + 4; // rows of the staging tile stay 16-byte aligned: the 2 x TS operands of a k step are 16-B LDS reads
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const bool active = tx <= ty && (uint32_t)(ty * TS) < nc; // blocks that touch the lower triangle of the nc x nc matrix
     float acc[TS][TS];
@@ -119,7 +120,7 @@ __device__ __forceinline__ void gram_lower(const float *__restrict__ X, uint32_t
 __device__ uint32_t prune_core(const float *__restrict__ X, uint32_t ld, const uint32_t *c_id, const float *c_d,
                                uint32_t nc, uint32_t limit, float alpha, float *tri /* TRI_ELEMS floats, LDS */,
                                uint32_t *s_sel /* [64] LDS */, uint32_t *s_cnt /* LDS */) {
-    float *stage = tri; // [KC][LDW] aliased: dead before tri is written
+    float *stage = static_cast<float *>(__builtin_assume_aligned(tri, 16)); // [KC][LDW] aliased: dead before tri is written
     const int tid = threadIdx.x;
     if (nc <= 32) gram_lower<2>(X, ld, c_id, nc, tri, stage);       // work ~ nc^2: small lists use small tiles
     else if (nc <= 64) gram_lower<4>(X, ld, c_id, nc, tri, stage);
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256) select_kernel(const float *__restrict__ X
                                                      float alpha, uint64_t *__restrict__ prop_key, uint32_t *__restrict__ prop_src,
                                                      const uint64_t *__restrict__ exp_keys, const uint32_t *__restrict__ exp_cnt,
                                                      uint32_t exp_cap) {
-    __shared__ float tri[TRI_ELEMS];
+    __shared__ __attribute__((aligned(16))) float tri[TRI_ELEMS];
     __shared__ uint32_t c_id[NCMAX];
     __shared__ float c_d[NCMAX];
     __shared__ uint32_t s_sel[64];
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(256) reverse_merge_kernel(const float *__restr
                                                             const uint32_t *__restrict__ srcs, uint32_t num,
                                                             const uint32_t *__restrict__ seg_start,
                                                             const uint32_t *__restrict__ nseg_p, float alpha) {
-    __shared__ float tri[TRI_ELEMS];
+    __shared__ __attribute__((aligned(16))) float tri[TRI_ELEMS];
     __shared__ uint64_t skey[NCMAX];
     __shared__ uint32_t c_id[NCMAX];
     __shared__ float c_d[NCMAX];
