@@ -61,8 +61,19 @@ __device__ __forceinline__ void gram_lower(const float *__restrict__ X, uint32_t
                                            float *tri, float *stage_) {
     float *stage = static_cast<float *>(__builtin_assume_aligned(stage_, 16));
     constexpr int KC = 32, LDW = NCMAX + 4; // rows of the staging tile stay 16-byte aligned: the 2 x TS operands of a k step are 16-B LDS reads
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const bool active = tx <= ty && (uint32_t)(ty * TS) < nc; // blocks that touch the lower triangle of the nc x nc matrix
+    // The blocks that touch the lower triangle of the nc x nc matrix — (ty, tx) with tx <= ty < ceil(nc / TS) — are handed to the FIRST
+    // threads of the workgroup in triangular order, so the multiply loop runs in ceil(ntiles / 64) waves (1 for the ~70 candidates of a
+    // full Vamana list) instead of in every wave that owns a row of a 16 x 16 thread grid (3 of 4 there, a handful of lanes each).
+    const int tid = threadIdx.x;
+    const int tdim = min(16, (int)((nc + TS - 1) / TS)), ntiles = tdim * (tdim + 1) / 2;
+    const bool active = tid < ntiles;
+    int ty = 0, tx = 0;
+    if (active) {
+        ty = (int)((sqrtf(8.f * (float)tid + 1.f) - 1.f) * 0.5f);
+        while (ty * (ty + 1) / 2 > tid) ty--;
+        while ((ty + 1) * (ty + 2) / 2 <= tid) ty++;
+        tx = tid - ty * (ty + 1) / 2;
+    }
     float acc[TS][TS];
 #pragma unroll
     for (int i = 0; i < TS; i++)
