@@ -33,8 +33,8 @@ import torch  # device memory, streams, events, torch.distributed (RCCL): plumbi
 
 WORKLOADS = {
     # name: rows per GPU, dims, M, efc, ef, synthetic params
-    # BASELINE metric config.  ef_construction 200: measured on 10M rows, recall@10 >= 0.955 needs ef = 80 on an
-    # efc = 128 graph (905 k QPS), ef = 56 on efc = 200 (1.08 M QPS, build 31 s), ef = 48 on efc = 320 (1.15 M, build 50 s)
+    # BASELINE metric config.  ef_construction 200: measured on 10M rows (final builder and kernel), recall@10 >= 0.955 needs ef = 56
+    # (0.9566, 1.15 M QPS, build 27 s); an efc = 320 graph (--efc 320) still needs ef = 56 (0.9635, 1.11 M QPS, build 41 s)
     "hnsw10m": dict(rows=10_000_000, d=768, M=32, efc=200, ef=128),
     "hnsw1m": dict(rows=1_000_000, d=768, M=32, efc=128, ef=128),     # BASELINE configs[1]
     "hnsw100m_shard8": dict(rows=12_500_000, d=768, M=32, efc=200, ef=128),  # BASELINE configs[3]: 100M x 768 = 8 shards of 12.5M (--gpus 8)
@@ -316,6 +316,7 @@ def main():
     ap.add_argument("--filter-selectivity", type=float, default=0.0,
                     help="side experiment (not the headline metric): metadata-filtered search with a seeded random allow-bitmap "
                          "of this density evaluated inside the traversal; recall is measured against the exact FILTERED top-k")
+    ap.add_argument("--efc", type=int, default=0, help="override the workload's ef_construction (graph build quality; 0 = the workload's value)")
     ap.add_argument("--filter-exact", action="store_true",
                     help="with --filter-selectivity: answer the filtered queries exactly (allowed rows compacted + f32 MFMA scan, "
                          "leann_backend_search_filtered_exact_batch_device) instead of walking the graph")
@@ -357,7 +358,7 @@ def main():
         return bench_scan(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log)
     if wl.get("kind") == "recompute":
         return bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log)
-    rows, d, M, efc = wl["rows"], wl["d"], wl["M"], wl["efc"]
+    rows, d, M, efc = wl["rows"], wl["d"], wl["M"], (args.efc or wl["efc"])
     ef_auto = str(args.ef).lower() == "auto"
     ef = wl["ef"] if ef_auto else (int(args.ef) or wl["ef"])
     backend = wl.get("backend", 0)
