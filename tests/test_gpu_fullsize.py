@@ -115,3 +115,53 @@ def test_fullsize_exact_filter_equals_masked_scan(full):
         for i in range(n_q):  # the walk's j-th best allowed distance is never better than the exact j-th best
             c = int(wc[i])
             assert (wd[i, :c] >= ed[i, :c] - 1e-6).all()
+
+
+def test_fullsize_recompute_properties(la, po, gpu, monkeypatch):
+    """BASELINE configs[2] at full size (10M passages x 256 bf16 features, W[256 x 768], 64 queries): the emission path equals the
+    score-slab path bit for bit, the winners' scores match the oracle's literal recompute (embed, then dot) within 1e-5, prefixes
+    are consistent, and the early filter (compacted row list) equals the masked pass over everything."""
+    L, chk = la.lib(), la._native.check
+    n, h, d, nq, k = ROWS, 256, 768, 64, K
+    dF, dW = la.DeviceArray((n, h), np.uint16), la.DeviceArray((h, d), np.uint16)
+    chk(L.leann_synth_features_device(SEED, h, 64, 4096, 1.0, 0, 0, n, dF.ptr, None))
+    chk(L.leann_synth_weights_device(SEED, h, d, dW.ptr, None))
+    W = po.synth_weights(SEED, h, d)
+    Q = po.recompute_encode(po.synth_features(SEED, h, 4096, 1.0, 1, 0, nq, r_int=64), W)
+    dQ = la.DeviceArray.from_host(Q)
+    r = C.c_void_p()
+    chk(L.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))
+
+    def search(kk, dM=None):
+        dk, ds, dc = la.DeviceArray((nq, kk), np.uint64), la.DeviceArray((nq, kk), np.float32), la.DeviceArray(nq, np.uint32)
+        chk(L.leann_recompute_search_batch_device(r, dQ.ptr, nq, kk, dM.ptr if dM is not None else None, dk.ptr, ds.ptr, dc.ptr, None))
+        la.sync()
+        return dk.to_host(), ds.to_host(), dc.to_host()
+
+    gk, gs, gc = search(k)
+    assert (gc == k).all() and (gk < n).all() and (np.diff(gs, axis=1) <= 0).all()
+    assert all(len(set(row.tolist())) == k for row in gk)
+    k5, s5, _ = search(5)
+    assert (k5 == gk[:, :5]).all() and (s5.view(np.uint32) == gs[:, :5].view(np.uint32)).all()   # prefix property
+    monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")                                                 # same kernel, slab + segment top-k
+    sk, ss, _ = search(k)
+    monkeypatch.delenv("LEANN_DEBUG_NO_EMIT")
+    assert (sk == gk).all() and (ss.view(np.uint32) == gs.view(np.uint32)).all()
+    # oracle on the winners (rows fetched back from HBM): score = <l2norm(W^T f), q>  (recompute.rs:96-103)
+    for i in (0, 17, 63):
+        rows = np.empty((k, h), np.uint16)
+        for j, pos in enumerate(gk[i]):
+            chk(L.leann_device_download(rows[j].ctypes.data, dF.ptr + int(pos) * h * 2, h * 2))
+        E = po.recompute_encode(rows, W)
+        assert np.abs(E @ Q[i] - gs[i]).max() <= 1e-5
+    # early filter: 1 % allowed through the compacted row list == the masked pass
+    rng = np.random.default_rng(5)
+    allowed = rng.random(n) < 0.01
+    dM = la.DeviceArray.from_host(np.packbits(allowed, bitorder="little"))
+    lk, ls, lc = search(k, dM)
+    monkeypatch.setenv("LEANN_RECOMPUTE_NO_LIST", "1")
+    fk, fs, fc = search(k, dM)
+    monkeypatch.delenv("LEANN_RECOMPUTE_NO_LIST")
+    assert (lk == fk).all() and (ls.view(np.uint32) == fs.view(np.uint32)).all() and (lc == fc).all()
+    assert allowed[lk.astype(np.int64)].all()
+    L.leann_recompute_close(r)
