@@ -35,7 +35,8 @@ enum {
     LEANN_ERR_FORMAT = 3,       /* FAISS / foreign format, hnsw.rs:24-32,57-69; compat.rs:15-38 */
     LEANN_ERR_DEVICE = 4,       /* HIP runtime / no GPU */
     LEANN_ERR_UNSUPPORTED = 5,  /* e.g. DiskANN incremental add, mod.rs:93-98 */
-    LEANN_ERR_IO = 6
+    LEANN_ERR_IO = 6,
+    LEANN_ERR_OVERFLOW = 7      /* a query ran out of visited-set space (defensive; see leann_backend_search_batch_device) */
 };
 
 const char *leann_last_error(void);
@@ -162,7 +163,9 @@ int leann_backend_graph_export(const leann_backend *h, uint8_t *levels, uint32_t
 /* Persist an in-memory index: "<stem>.index" / ".diskann" */
 int leann_backend_save(const leann_backend *h, const char *index_path_stem);
 
-/* d_stats: optional [nq x 4] u32 (evals, hops0, hopsU, overflow) */
+/* d_stats: optional [nq x 4] u32: distance evaluations, level-0 hops, upper-level hops, visited-set level (0 = the LDS
+ * table sufficed, 1 / 2 = the query moved to a pooled table in HBM, 3 = even the last level filled up: that query's count is 0
+ * and the host-pointer entry points return LEANN_ERR_OVERFLOW; the pools are sized so that 3 cannot occur). */
 int leann_backend_search_batch_device(const leann_backend *h, const float *d_queries, size_t nq,
                                       size_t top_k, size_t complexity, uint64_t *d_keys,
                                       float *d_dists, uint32_t *d_counts, uint32_t *d_stats,

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <strings.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -27,6 +28,24 @@ extern "C" void leann_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *leann_last_error(void) { return g_err; }
+void leann_log(int level, const char *fmt, ...) {
+    static const int threshold = [] {
+        const char *e = getenv("LEANN_LOG");
+        if (!e) return (int)LEANN_LOG_WARN;
+        if (!strcasecmp(e, "error")) return (int)LEANN_LOG_ERROR;
+        if (!strcasecmp(e, "info")) return (int)LEANN_LOG_INFO;
+        if (!strcasecmp(e, "debug") || !strcasecmp(e, "trace")) return (int)LEANN_LOG_DEBUG;
+        return (int)LEANN_LOG_WARN;
+    }();
+    if (level > threshold) return;
+    static const char *names[] = {"ERROR", "WARN", "INFO", "DEBUG"};
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "%s leann_hip: %s\n", names[level < 0 ? 0 : (level > 3 ? 3 : level)], buf);
+}
 extern "C" const char *leann_version(void) { return "leann-rs_amd 0.1 (gfx950)"; }
 
 // ---- raw device helpers ---------------------------------------------------------------------------
@@ -73,20 +92,62 @@ static void ws_free(Workspace *w) {
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }
+static uint32_t debug_bits(const char *name, uint32_t lo, uint32_t hi, uint32_t dflt) { // test hooks: force tiny visited tables
+    if (const char *e = getenv(name)) {
+        int v = atoi(e);
+        if (v >= (int)lo && v <= (int)hi) return (uint32_t)v;
+    }
+    return dflt;
+}
+// Pool 1: GPOOL_TABLES tables of 2^GPOOL_BITS slots (512 MB) for queries that outgrow their LDS table.  Pool 2, only when the
+// index has more rows than a pool-1 table holds at 75 % load: a few tables of >= (n + 128) / 0.75 slots each (<= 1 GiB in all), so
+// that no search can run out of visited-set space whatever the beam (search.cuh).
 static int ensure_gpool(leann_backend *h) {
     std::lock_guard<std::mutex> lk(h->mu);
     if (h->gpool) return LEANN_OK;
-    unsigned long long *p = nullptr;
-    uint32_t *lock = nullptr;
-    const size_t slots = (size_t)GPOOL_TABLES << GPOOL_BITS;
-    HIP_CHECK_RET(hipMalloc((void **)&p, slots * 8));
-    HIP_CHECK_RET(hipMalloc((void **)&lock, (GPOOL_TABLES + 4) * 4));
-    HIP_CHECK_RET(hipMemset(p, 0, slots * 8)); // generation 0 is never issued
-    HIP_CHECK_RET(hipMemset(lock, 0, (GPOOL_TABLES + 4) * 4));
+    unsigned long long *p = nullptr, *p2 = nullptr;
+    uint32_t *lock = nullptr, *lock2 = nullptr;
+    const uint32_t bits = debug_bits("LEANN_DEBUG_GPOOL_BITS", 6, GPOOL_BITS, GPOOL_BITS), tables = GPOOL_TABLES;
+    const size_t slots = (size_t)tables << bits;
+    uint32_t bits2 = 0, tables2 = 0;
+    const uint64_t need = h->g.n + 128;
+    if (need > (1ull << bits) - (1ull << (bits - 2))) {
+        bits2 = bits + 1;
+        while (bits2 < 31 && (1ull << bits2) - (1ull << (bits2 - 2)) < need) bits2++;
+        bits2 = debug_bits("LEANN_DEBUG_GPOOL2_BITS", 6, 31, bits2);
+        const uint64_t per = 8ull << bits2;
+        tables2 = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(2, (1ull << 30) / per));
+    }
+    auto fail = [&](const char *what) {
+        (void)hipFree(p); (void)hipFree(p2); (void)hipFree(lock); (void)hipFree(lock2);
+        leann_set_error("visited-table pool: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
+        return LEANN_ERR_DEVICE;
+    };
+    if (hipMalloc((void **)&p, slots * 8) != hipSuccess) return fail("hipMalloc");
+    if (hipMalloc((void **)&lock, (tables + 4) * 4) != hipSuccess) return fail("hipMalloc");
+    if (hipMemset(p, 0, slots * 8) != hipSuccess) return fail("hipMemset"); // generation 0 is never issued
+    if (hipMemset(lock, 0, (tables + 4) * 4) != hipSuccess) return fail("hipMemset");
+    if (tables2) {
+        if (hipMalloc((void **)&p2, ((size_t)tables2 << bits2) * 8) != hipSuccess) return fail("hipMalloc");
+        if (hipMalloc((void **)&lock2, tables2 * 4) != hipSuccess) return fail("hipMalloc");
+        if (hipMemset(p2, 0, ((size_t)tables2 << bits2) * 8) != hipSuccess) return fail("hipMemset");
+        if (hipMemset(lock2, 0, tables2 * 4) != hipSuccess) return fail("hipMemset");
+    }
     h->gpool_lock = lock;
-    h->gpool_ctr = lock + GPOOL_TABLES;
+    h->gpool_ctr = lock + tables;
+    h->gpool_bits = bits;
+    h->gpool_tables = tables;
+    h->gpool2 = p2;
+    h->gpool2_lock = lock2;
+    h->gpool2_bits = bits2;
+    h->gpool2_tables = tables2;
     h->gpool = p;
     return LEANN_OK;
+}
+static void set_pool_args(const leann_backend *h, SearchArgs &a) {
+    a.gpool = h->gpool; a.gpool_lock = h->gpool_lock; a.gpool_ctr = h->gpool_ctr;
+    a.gpool_bits = h->gpool_bits; a.gpool_tables = h->gpool_tables;
+    a.gpool2 = h->gpool2; a.gpool2_lock = h->gpool2_lock; a.gpool2_bits = h->gpool2_bits; a.gpool2_tables = h->gpool2_tables;
 }
 
 void leann_internal_free_graph(leann_backend *h) {
@@ -97,6 +158,8 @@ void leann_internal_free_graph(leann_backend *h) {
     (void)hipFree(h->d_levels);
     (void)hipFree(h->gpool);
     (void)hipFree(h->gpool_lock);
+    (void)hipFree(h->gpool2);
+    (void)hipFree(h->gpool2_lock);
     (void)hipFree(h->Wf32);
     for (auto &kv : h->proj_scratch) (void)hipFree(kv.second.first);
 }
@@ -220,7 +283,7 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
         a.hash_bits = getenv("LEANN_DEBUG_HASH_BITS") ? pick_hash_bits(a.ef) : (a.ef <= 64 ? 12u : pick_hash_bits(a.ef));
         int rc = ensure_gpool(h);
         if (rc) return rc;
-        a.gpool = h->gpool; a.gpool_lock = h->gpool_lock; a.gpool_ctr = h->gpool_ctr;
+        set_pool_args(h, a);
         const float *G = nullptr;
         rc = project_queries(h, a.queries, a.nq, st, &G);
         if (rc) return rc;
@@ -238,9 +301,7 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
     a.hash_bits = pick_hash_bits(a.ef);
     int rc = ensure_gpool(h);
     if (rc) return rc;
-    a.gpool = h->gpool;
-    a.gpool_lock = h->gpool_lock;
-    a.gpool_ctr = h->gpool_ctr;
+    set_pool_args(h, a);
     const GraphView &g = h->g;
     int T = (int)((g.ld + 255) / 256);
     switch (T) {
@@ -540,18 +601,25 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
         leann_set_error("search: device error: %s", hipGetErrorString(hipGetLastError()));
         return fail(LEANN_ERR_DEVICE);
     }
+    size_t n_lost = 0;
     {
         std::lock_guard<std::mutex> lk(h->mu);
         for (size_t i = 0; i < nq; i++) {
             h->stats.n_dist_evals += hstats[i * 4 + 0];
             h->stats.n_hops_base += hstats[i * 4 + 1];
             h->stats.n_hops_upper += hstats[i * 4 + 2];
-            h->stats.n_table_overflow += hstats[i * 4 + 3];
+            h->stats.n_table_overflow += hstats[i * 4 + 3] ? 1 : 0;
+            n_lost += hstats[i * 4 + 3] == 3;
             h->stats.algorithmic_bytes += (uint64_t)hstats[i * 4 + 0] * (h->g.feat_h ? h->g.row_bytes : d * 4) + (uint64_t)hstats[i * 4 + 1] * h->g.M0 * 4 +
                                           (uint64_t)hstats[i * 4 + 2] * h->g.M * 4;
         }
         h->stats.n_queries += nq;
         h->free_ws.push_back(w);
+    }
+    if (n_lost) { // search.cuh: the last visited-table level filled up (not reachable with the pools ensure_gpool sizes)
+        leann_set_error("search: %zu of %zu queries ran out of visited-set space at complexity %zu; lower the complexity", n_lost, nq,
+                        (size_t)a.ef);
+        return LEANN_ERR_OVERFLOW;
     }
     return LEANN_OK;
 }
@@ -625,31 +693,40 @@ struct Coalescer {
     }
 };
 
+// Safe against searches in flight: the handle's coalescer is swapped out under h->mu, the lock is RELEASED, and only then is the old
+// dispatcher stopped and joined (it drains its queue first; its launches take h->mu themselves).  Callers hold a shared_ptr, so the
+// object outlives every waiter; a caller that arrives after `stop` answers its query directly.
 extern "C" int leann_backend_set_coalescing(leann_backend *h, uint32_t wait_us, uint32_t max_batch) {
     if (!h) { leann_set_error("leann_backend_set_coalescing: null handle"); return LEANN_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (h->coalescer) { // reconfigure or disable
-        Coalescer *c = h->coalescer;
-        { std::lock_guard<std::mutex> l2(c->mu); c->stop = true; }
-        c->cv_submit.notify_all();
-        c->th.join();
-        delete c;
-        h->coalescer = nullptr;
+    std::shared_ptr<Coalescer> fresh, old;
+    if (!(wait_us == 0 && max_batch == 0)) {
+        fresh = std::make_shared<Coalescer>();
+        fresh->h = h;
+        fresh->wait_us = wait_us;
+        fresh->max_batch = max_batch ? max_batch : 4096;
+        Coalescer *c = fresh.get();
+        fresh->th = std::thread([c] { c->run(); });
     }
-    if (wait_us == 0 && max_batch == 0) return LEANN_OK;
-    Coalescer *c = new Coalescer();
-    c->h = h;
-    c->wait_us = wait_us;
-    c->max_batch = max_batch ? max_batch : 4096;
-    c->th = std::thread([c] { c->run(); });
-    h->coalescer = c;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        old.swap(h->coalescer);
+        h->coalescer = fresh;
+    }
+    if (old) {
+        { std::lock_guard<std::mutex> l2(old->mu); old->stop = true; }
+        old->cv_submit.notify_all();
+        old->th.join();
+    }
     return LEANN_OK;
 }
-extern "C" int leann_backend_coalescing_stats(const leann_backend *h, uint64_t *n_launches, uint64_t *n_queries) {
-    if (!h || !h->coalescer) { leann_set_error("coalescing is not enabled on this handle"); return LEANN_ERR_INVALID; }
-    std::lock_guard<std::mutex> l2(h->coalescer->mu);
-    if (n_launches) *n_launches = h->coalescer->n_launches;
-    if (n_queries) *n_queries = h->coalescer->n_queries;
+extern "C" int leann_backend_coalescing_stats(const leann_backend *hc, uint64_t *n_launches, uint64_t *n_queries) {
+    leann_backend *h = const_cast<leann_backend *>(hc);
+    std::shared_ptr<Coalescer> c;
+    if (h) { std::lock_guard<std::mutex> lk(h->mu); c = h->coalescer; }
+    if (!c) { leann_set_error("coalescing is not enabled on this handle"); return LEANN_ERR_INVALID; }
+    std::lock_guard<std::mutex> l2(c->mu);
+    if (n_launches) *n_launches = c->n_launches;
+    if (n_queries) *n_queries = c->n_queries;
     return LEANN_OK;
 }
 
@@ -657,15 +734,18 @@ extern "C" int leann_backend_search(const leann_backend *hc, const float *query,
                                     uint64_t *keys, float *dists, size_t *n_out) {
     if (!n_out) { leann_set_error("leann_backend_search: n_out is null"); return LEANN_ERR_INVALID; }
     leann_backend *h = const_cast<leann_backend *>(hc);
-    if (h && h->coalescer && query && keys && dists && top_k > 0 && h->g.n > 0) {
-        Coalescer *c = h->coalescer;
+    std::shared_ptr<Coalescer> c;
+    if (h && query && keys && dists && top_k > 0 && h->g.n > 0) { std::lock_guard<std::mutex> lk(h->mu); c = h->coalescer; }
+    if (c) {
         PendingQuery p{query, top_k, complexity, keys, dists, n_out};
         std::unique_lock<std::mutex> lk(c->mu);
-        c->queue.push_back(&p);
-        c->cv_submit.notify_one();
-        c->cv_done.wait(lk, [&] { return p.done; });
-        if (p.rc) leann_set_error("%s", p.err.c_str());
-        return p.rc;
+        if (!c->stop) { // a stopped dispatcher takes no new work: fall through to the direct call
+            c->queue.push_back(&p);
+            c->cv_submit.notify_one();
+            c->cv_done.wait(lk, [&] { return p.done; });
+            if (p.rc) leann_set_error("%s", p.err.c_str());
+            return p.rc;
+        }
     }
     uint32_t cnt = 0;
     int rc = leann_backend_search_batch(h, query, 1, top_k, complexity, keys, dists, &cnt);
@@ -686,28 +766,51 @@ extern "C" int leann_backend_search_filtered(const leann_backend *hc, const floa
 }
 
 // ---- in-memory construction from host arrays ----------------------------------------------------------
-static int upload_rows_padded(const float *vectors, size_t n, size_t d, size_t ld, float **out) {
-    float *dX = nullptr;
-    HIP_CHECK_RET(hipMalloc((void **)&dX, std::max<size_t>(n * ld, 4) * 4));
-    if (n) {
-        if (ld == d) HIP_CHECK_RET(hipMemcpy(dX, vectors, n * d * 4, hipMemcpyHostToDevice));
-        else {
-            HIP_CHECK_RET(hipMemset(dX, 0, n * ld * 4));
-            HIP_CHECK_RET(hipMemcpy2D(dX, ld * 4, vectors, d * 4, d * 4, n, hipMemcpyHostToDevice));
+// Every array is checked against n BEFORE anything is uploaded: the traversal kernel indexes rows by neighbour id, upper lists by
+// upper_off[node] + level - 1 and trusts both (search.cuh), so one bad entry in an index file would be an out-of-bounds read on the GPU.
+static const char *validate_graph(size_t n, uint32_t M, uint32_t M0, uint32_t max_level, uint32_t entry, const uint8_t *levels,
+                                  const uint32_t *upper_off, const uint32_t *adj0, const uint32_t *adjU, size_t n_upper_lists) {
+    if (M == 0 || M0 == 0 || M > 64 || M0 > 64) return "graph degree outside [1, 64]";
+    if (max_level > 15) return "max_level > 15";
+    if (n == 0) return nullptr;
+    if (entry >= n) return "entry point is not a row of the index";
+    if (!levels && (max_level != 0 || n_upper_lists != 0)) return "upper levels without a level table";
+    if (n_upper_lists && !adjU) return "upper lists missing";
+    if (levels && levels[entry] < max_level) return "the entry point does not reach max_level";
+    for (size_t v = 0; v < n; v++) {
+        const uint32_t lv = levels ? levels[v] : 0;
+        if (lv > 15) return "node level > 15";
+        if (lv && (size_t)upper_off[v] + lv > n_upper_lists) return "upper_off + level runs past the upper lists";
+        const uint32_t *l0 = adj0 + v * (size_t)M0;
+        for (uint32_t j = 0; j < M0; j++)
+            if (l0[j] != LEANN_EMPTY && l0[j] >= n) return "level-0 neighbour id >= n";
+        for (uint32_t l = 1; l <= lv; l++) {
+            const uint32_t *lu = adjU + ((size_t)upper_off[v] + l - 1) * M;
+            for (uint32_t j = 0; j < M; j++) {
+                const uint32_t e = lu[j];
+                if (e == LEANN_EMPTY) continue;
+                if (e >= n) return "upper-level neighbour id >= n";
+                if (levels[e] < l) return "upper-level neighbour does not exist on that level";
+            }
         }
     }
-    *out = dX;
-    return LEANN_OK;
+    return nullptr;
 }
 
-extern "C" int leann_backend_from_arrays(int backend, const float *vectors, size_t n, size_t dims, uint32_t M,
-                                         uint32_t M0, uint32_t max_level, uint32_t entry, const uint8_t *levels,
-                                         const uint32_t *upper_off, const uint32_t *adj0, const uint32_t *adjU,
-                                         size_t n_upper_lists, int device, uint64_t key_offset, leann_backend **out) {
-    if (!out || dims == 0 || dims > 2048 || M == 0 || M0 == 0 || n >= (1ull << 31) || (n && (!vectors || !adj0 || !upper_off)) ||
-        (n && entry >= n)) {
+int leann_internal_from_host(int backend, size_t n, size_t dims, uint32_t M, uint32_t M0, uint32_t max_level, uint32_t entry,
+                             const uint8_t *levels, const uint32_t *upper_off, const uint32_t *adj0, const uint32_t *adjU,
+                             size_t n_upper_lists, const float *vectors, const unsigned char *feat_rows, uint32_t feat_h, uint32_t row_bytes,
+                             const float *Wf32, int device, uint64_t key_offset, leann_backend **out) {
+    const bool feat = feat_rows != nullptr;
+    if (!out || dims == 0 || dims > 2048 || n >= (1ull << 31) || (n && ((!vectors && !feat) || !adj0 || !upper_off)) ||
+        (backend != LEANN_BACKEND_HNSW && backend != LEANN_BACKEND_DISKANN) ||
+        (feat && (!Wf32 || feat_h == 0 || (feat_h & 3) || feat_h > 1024 || row_bytes < 2 * feat_h + 4 || (row_bytes & 7)))) {
         leann_set_error("leann_backend_from_arrays: invalid arguments");
         return LEANN_ERR_INVALID;
+    }
+    if (const char *why = validate_graph(n, M, M0, max_level, entry, levels, upper_off, adj0, adjU, n_upper_lists)) {
+        leann_set_error("leann_backend_from_arrays: inconsistent graph arrays: %s", why);
+        return LEANN_ERR_FORMAT;
     }
     int ndev = 0;
     leann_device_count(&ndev);
@@ -720,40 +823,62 @@ extern "C" int leann_backend_from_arrays(int backend, const float *vectors, size
     h->kind = backend;
     h->device = device;
     h->key_offset = key_offset;
-    size_t ld = (dims + 3) & ~(size_t)3;
-    float *dX = nullptr;
-    int rc = upload_rows_padded(vectors, n, dims, ld, &dX);
-    if (rc) { delete h; return rc; }
-    uint32_t *d_adj0 = nullptr, *d_adjU = nullptr, *d_uo = nullptr;
-    size_t nn = std::max<size_t>(n, 1), nu = std::max<size_t>(n_upper_lists, 1);
-    if (hipMalloc((void **)&d_adj0, nn * M0 * 4) != hipSuccess || hipMalloc((void **)&d_adjU, nu * M * 4) != hipSuccess ||
-        hipMalloc((void **)&d_uo, nn * 4) != hipSuccess || hipMalloc((void **)&h->d_levels, nn) != hipSuccess) {
-        leann_set_error("hipMalloc failed for graph arrays");
-        delete h;
-        return LEANN_ERR_DEVICE;
-    }
-    HIP_CHECK_RET(hipMemset(d_adjU, 0xFF, nu * M * 4));
-    if (n) {
-        HIP_CHECK_RET(hipMemcpy(d_adj0, adj0, n * M0 * 4, hipMemcpyHostToDevice));
-        HIP_CHECK_RET(hipMemcpy(d_uo, upper_off, n * 4, hipMemcpyHostToDevice));
-        if (levels) HIP_CHECK_RET(hipMemcpy(h->d_levels, levels, n, hipMemcpyHostToDevice));
-        else HIP_CHECK_RET(hipMemset(h->d_levels, 0, n));
-        if (n_upper_lists) HIP_CHECK_RET(hipMemcpy(d_adjU, adjU, n_upper_lists * M * 4, hipMemcpyHostToDevice));
-    }
-    h->g.X = dX;
-    h->g.adj0 = d_adj0;
-    h->g.adjU = d_adjU;
-    h->g.upper_off = d_uo;
     h->g.n = n;
     h->g.d = (uint32_t)dims;
-    h->g.ld = (uint32_t)ld;
+    h->g.ld = (uint32_t)((dims + 3) & ~(size_t)3);
     h->g.M = M;
     h->g.M0 = M0;
     h->g.max_level = max_level;
     h->g.entry = entry;
     h->n_upper_lists = n_upper_lists;
+    // every allocation lands in the handle at once, so that one leann_backend_close frees whatever a failure leaves behind
+    auto fail = [&](const char *what) {
+        leann_set_error("leann_backend_from_arrays: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
+        leann_backend_close(h);
+        return LEANN_ERR_DEVICE;
+    };
+    const size_t nn = std::max<size_t>(n, 1), nu = std::max<size_t>(n_upper_lists, 1), ld = h->g.ld;
+    if (feat) {
+        h->g.feat_h = feat_h;
+        h->g.row_bytes = row_bytes;
+        if (hipMalloc((void **)&h->g.X, nn * row_bytes) != hipSuccess) return fail("hipMalloc(rows)");
+        if (n && hipMemcpy((void *)h->g.X, feat_rows, n * (size_t)row_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("upload of the feature rows");
+        if (hipMalloc((void **)&h->Wf32, (size_t)feat_h * dims * 4) != hipSuccess) return fail("hipMalloc(weights)");
+        if (hipMemcpy(h->Wf32, Wf32, (size_t)feat_h * dims * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("upload of the weights");
+    } else {
+        if (hipMalloc((void **)&h->g.X, std::max<size_t>(n * ld, 4) * 4) != hipSuccess) return fail("hipMalloc(rows)");
+        if (n) {
+            if (ld == dims) { if (hipMemcpy((void *)h->g.X, vectors, n * dims * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("upload of the rows"); }
+            else if (hipMemset((void *)h->g.X, 0, n * ld * 4) != hipSuccess ||
+                     hipMemcpy2D((void *)h->g.X, ld * 4, vectors, dims * 4, dims * 4, n, hipMemcpyHostToDevice) != hipSuccess) return fail("upload of the rows");
+        }
+    }
+    if (hipMalloc((void **)&h->g.adj0, nn * M0 * 4) != hipSuccess || hipMalloc((void **)&h->g.adjU, nu * M * 4) != hipSuccess ||
+        hipMalloc((void **)&h->g.upper_off, nn * 4) != hipSuccess || hipMalloc((void **)&h->d_levels, nn) != hipSuccess)
+        return fail("hipMalloc(graph arrays)");
+    if (hipMemset((void *)h->g.adjU, 0xFF, nu * M * 4) != hipSuccess) return fail("hipMemset");
+    if (n) {
+        if (hipMemcpy((void *)h->g.adj0, adj0, n * M0 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy((void *)h->g.upper_off, upper_off, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            (levels ? hipMemcpy(h->d_levels, levels, n, hipMemcpyHostToDevice) : hipMemset(h->d_levels, 0, n)) != hipSuccess ||
+            (n_upper_lists && hipMemcpy((void *)h->g.adjU, adjU, n_upper_lists * M * 4, hipMemcpyHostToDevice) != hipSuccess))
+            return fail("upload of the graph arrays");
+    }
     *out = h;
     return LEANN_OK;
+}
+
+extern "C" int leann_backend_from_arrays(int backend, const float *vectors, size_t n, size_t dims, uint32_t M,
+                                         uint32_t M0, uint32_t max_level, uint32_t entry, const uint8_t *levels,
+                                         const uint32_t *upper_off, const uint32_t *adj0, const uint32_t *adjU,
+                                         size_t n_upper_lists, int device, uint64_t key_offset, leann_backend **out) {
+    try {
+        return leann_internal_from_host(backend, n, dims, M, M0, max_level, entry, levels, upper_off, adj0, adjU, n_upper_lists, vectors,
+                                        nullptr, 0, 0, nullptr, device, key_offset, out);
+    } catch (const std::exception &e) {
+        leann_set_error("leann_backend_from_arrays: %s", e.what());
+        return LEANN_ERR_IO;
+    }
 }
 
 extern "C" int leann_backend_graph_info(const leann_backend *h, uint64_t *info) {
@@ -781,125 +906,3 @@ extern "C" int leann_backend_graph_export(const leann_backend *h, uint8_t *level
     return LEANN_OK;
 }
 
-// ---- index files ------------------------------------------------------------------------------------
-// "<stem minus .leann>.index" (hnsw.rs:19) / ".diskann" (diskann.rs:22): Path::with_extension replaces
-// the text after the last '.' of the file name.
-static std::string with_extension(const std::string &stem, const char *ext) {
-    size_t slash = stem.find_last_of('/');
-    size_t dot = stem.find_last_of('.');
-    std::string base = (dot != std::string::npos && (slash == std::string::npos || dot > slash) && dot != slash + 1)
-                           ? stem.substr(0, dot) : stem;
-    return base + "." + ext;
-}
-std::string leann_internal_index_file(const char *stem, int backend) {
-    return with_extension(stem, backend == LEANN_BACKEND_DISKANN ? "diskann" : "index");
-}
-
-#pragma pack(push, 1)
-struct FileHeader {
-    char magic[8]; // "LEANNGX1"
-    uint32_t version, kind;
-    uint64_t n;
-    uint32_t d, M, M0, max_level, entry, efc;
-    float alpha;
-    uint32_t reserved0;
-    uint64_t n_upper_lists;
-    uint8_t pad[64];
-};
-#pragma pack(pop)
-
-extern "C" int leann_backend_save(const leann_backend *h, const char *index_path_stem) {
-    if (!h || !index_path_stem) { leann_set_error("leann_backend_save: null argument"); return LEANN_ERR_INVALID; }
-    if (h->g.feat_h) { leann_set_error("leann_backend_save: a recompute-on index holds no vectors to save"); return LEANN_ERR_UNSUPPORTED; }
-    std::string path = leann_internal_index_file(index_path_stem, h->kind);
-    const size_t n = h->g.n, d = h->g.d;
-    std::vector<uint8_t> levels(std::max<size_t>(n, 1));
-    std::vector<uint32_t> uo(std::max<size_t>(n, 1)), a0(std::max<size_t>(n * h->g.M0, 1)),
-        aU(std::max<size_t>(h->n_upper_lists * h->g.M, 1));
-    std::vector<float> X(std::max<size_t>(n * d, 1));
-    int rc = leann_backend_graph_export(h, levels.data(), uo.data(), a0.data(), aU.data(), X.data());
-    if (rc) return rc;
-    FILE *f = fopen(path.c_str(), "wb");
-    if (!f) { leann_set_error("cannot create %s", path.c_str()); return LEANN_ERR_IO; }
-    FileHeader hd{};
-    memcpy(hd.magic, "LEANNGX1", 8);
-    hd.version = 1; hd.kind = (uint32_t)h->kind; hd.n = n; hd.d = (uint32_t)d; hd.M = h->g.M; hd.M0 = h->g.M0;
-    hd.max_level = h->g.max_level; hd.entry = h->g.entry; hd.efc = h->efc; hd.alpha = h->alpha;
-    hd.n_upper_lists = h->n_upper_lists;
-    bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1;
-    ok = ok && (n == 0 || fwrite(levels.data(), 1, n, f) == n);
-    ok = ok && (n == 0 || fwrite(uo.data(), 4, n, f) == n);
-    ok = ok && (n == 0 || fwrite(a0.data(), 4, n * h->g.M0, f) == n * h->g.M0);
-    ok = ok && (h->n_upper_lists == 0 || fwrite(aU.data(), 4, h->n_upper_lists * h->g.M, f) == h->n_upper_lists * h->g.M);
-    ok = ok && (n == 0 || fwrite(X.data(), 4, n * d, f) == n * d);
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) { leann_set_error("short write to %s", path.c_str()); return LEANN_ERR_IO; }
-    return LEANN_OK;
-}
-
-static int parse_device(const char *spec) {
-    if (!spec || !*spec) return 0;
-    return atoi(spec);
-}
-
-extern "C" int leann_backend_open(const char *index_path_stem, int backend, size_t dims, const char *device_spec,
-                                  leann_backend **out) {
-    if (!index_path_stem || !out) { leann_set_error("leann_backend_open: null argument"); return LEANN_ERR_INVALID; }
-    if (backend != LEANN_BACKEND_HNSW && backend != LEANN_BACKEND_DISKANN) {
-        leann_set_error("Unknown backend: %d", backend); // searcher.rs:98
-        return LEANN_ERR_INVALID;
-    }
-    std::string path = leann_internal_index_file(index_path_stem, backend);
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) {
-        if (backend == LEANN_BACKEND_HNSW) // hnsw.rs:34-40
-            leann_set_error("Index file not found: \"%s\"\nRun 'leann build' to create an index first.", path.c_str());
-        else // diskann.rs:26-32
-            leann_set_error("DiskANN index not found: \"%s\"\nRun 'leann build' with --backend-name diskann to create an index first.", path.c_str());
-        return LEANN_ERR_NOT_FOUND;
-    }
-    FileHeader hd{};
-    size_t got = fread(&hd, 1, sizeof(hd), f);
-    if (got >= 4) { // compat.rs:15-38 — FAISS (Python LEANN) magic sniff, hnsw.rs:24-32
-        const unsigned char *m = (const unsigned char *)&hd;
-        if ((m[0] == 'I' && m[1] == 'x') || !memcmp(m, "CSR\0", 4) || !memcmp(m, "HNSW", 4)) {
-            fclose(f);
-            leann_set_error("This index was built with Python LEANN (FAISS format).\n"
-                            "Rust LEANN uses usearch which has a different binary format.\n\n"
-                            "To use this index with Rust LEANN, you need to rebuild it:\n"
-                            "  leann build <name> --docs <path> --force\n\n"
-                            "The passages and metadata files are compatible and will be preserved.");
-            return LEANN_ERR_FORMAT;
-        }
-    }
-    if (got != sizeof(hd) || memcmp(hd.magic, "LEANNGX1", 8) != 0 || hd.version != 1) {
-        fclose(f);
-        // hnsw.rs:57-69
-        leann_set_error("Failed to load index: incompatible format.\n"
-                        "This may be a FAISS index from Python LEANN, or a usearch/diskann-rs file written by stock leann-rs.\n"
-                        "Rebuild with: leann build <name> --docs <path> --force\n\n"
-                        "Original error: bad magic/header/version in %s", path.c_str());
-        return LEANN_ERR_FORMAT;
-    }
-    if (dims && hd.d != dims) {
-        fclose(f);
-        leann_set_error("index has %u dimensions, expected %zu", hd.d, dims);
-        return LEANN_ERR_FORMAT;
-    }
-    const size_t n = hd.n, d = hd.d;
-    std::vector<uint8_t> levels(std::max<size_t>(n, 1));
-    std::vector<uint32_t> uo(std::max<size_t>(n, 1)), a0(std::max<size_t>(n * hd.M0, 1)),
-        aU(std::max<size_t>(hd.n_upper_lists * hd.M, 1));
-    std::vector<float> X(std::max<size_t>(n * d, 1));
-    bool ok = (n == 0 || fread(levels.data(), 1, n, f) == n);
-    ok = ok && (n == 0 || fread(uo.data(), 4, n, f) == n);
-    ok = ok && (n == 0 || fread(a0.data(), 4, n * hd.M0, f) == n * hd.M0);
-    ok = ok && (hd.n_upper_lists == 0 || fread(aU.data(), 4, hd.n_upper_lists * hd.M, f) == hd.n_upper_lists * hd.M);
-    ok = ok && (n == 0 || fread(X.data(), 4, n * d, f) == n * d);
-    fclose(f);
-    if (!ok) { leann_set_error("Failed to load index: truncated file %s", path.c_str()); return LEANN_ERR_FORMAT; }
-    int rc = leann_backend_from_arrays(backend, X.data(), n, d, hd.M, hd.M0, hd.max_level, hd.entry, levels.data(),
-                                       uo.data(), a0.data(), aU.data(), hd.n_upper_lists, parse_device(device_spec), 0, out);
-    if (rc == LEANN_OK) { (*out)->efc = hd.efc; (*out)->alpha = hd.alpha; }
-    return rc;
-}

@@ -397,6 +397,19 @@ struct Builder {
     uint64_t *exp_keys = nullptr; uint32_t *exp_cnt = nullptr; // Vamana only
     void *cub_tmp = nullptr; size_t cub_bytes = 0;
     hipStream_t st = nullptr;
+    Builder() = default;
+    Builder(const Builder &) = delete;
+    ~Builder() { // every exit of build_on_device, including the error returns, releases the scratch and the stream
+        if (st) (void)hipStreamSynchronize(st);
+        void *ps[] = {cand_keys, cand_d, cand_cnt, candU_keys, candU_d, candU_cnt, d_rowsU, prop_key, prop_key2,
+                      prop_src, prop_src2, seg_start, nseg, cub_tmp, d_order, adjd0, adjdU, exp_keys, exp_cnt};
+        for (void *p : ps) (void)hipFree(p);
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+struct DevTmp { // small scoped device allocation
+    void *p = nullptr;
+    ~DevTmp() { (void)hipFree(p); }
 };
 
 #define BCHECK(expr)                                                                           \
@@ -455,11 +468,6 @@ static int builder_alloc_scratch(Builder &b, size_t bmax) {
     b.cub_bytes = tmp;
     BCHECK(hipMalloc(&b.cub_tmp, tmp));
     return LEANN_OK;
-}
-static void builder_free_scratch(Builder &b) {
-    void *ps[] = {b.cand_keys, b.cand_d, b.cand_cnt, b.candU_keys, b.candU_d, b.candU_cnt, b.d_rowsU, b.prop_key, b.prop_key2,
-                  b.prop_src, b.prop_src2, b.seg_start, b.nseg, b.cub_tmp, b.d_order, b.adjd0, b.adjdU, b.exp_keys, b.exp_cnt};
-    for (void *p : ps) (void)hipFree(p);
 }
 
 // Insert order[s0 .. n) into the graph that already holds order[0 .. s0).
@@ -592,23 +600,22 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
         uint32_t first = 0;
         if (h->kind == LEANN_BACKEND_DISKANN) {
             // medoid: closest row to the mean direction, by the index metric (ties -> lower id)
-            float *mean = nullptr; uint64_t *mk = nullptr; float *ms = nullptr; uint32_t *mc = nullptr;
-            BCHECK(hipMalloc((void **)&mean, h->g.ld * 4));
-            BCHECK(hipMalloc((void **)&mk, 8)); BCHECK(hipMalloc((void **)&ms, 4)); BCHECK(hipMalloc((void **)&mc, 4));
+            DevTmp t_mean, t_mk, t_ms, t_mc, t_part;
             const uint32_t S = 1024;
-            double *part = nullptr;
-            BCHECK(hipMalloc((void **)&part, (size_t)S * h->g.ld * 8));
+            BCHECK(hipMalloc(&t_mean.p, h->g.ld * 4));
+            BCHECK(hipMalloc(&t_mk.p, 8)); BCHECK(hipMalloc(&t_ms.p, 4)); BCHECK(hipMalloc(&t_mc.p, 4));
+            BCHECK(hipMalloc(&t_part.p, (size_t)S * h->g.ld * 8));
+            float *mean = (float *)t_mean.p; uint64_t *mk = (uint64_t *)t_mk.p; float *ms = (float *)t_ms.p; uint32_t *mc = (uint32_t *)t_mc.p;
+            double *part = (double *)t_part.p;
             hipLaunchKernelGGL(col_partial_kernel, dim3((h->g.ld + 63) / 64, S), dim3(64), 0, b.st, h->g.X, n, h->g.d, h->g.ld, S, part);
             hipLaunchKernelGGL(col_mean_kernel, dim3((h->g.ld + 63) / 64), dim3(64), 0, b.st, part, n, h->g.ld, S, mean);
             BCHECK(hipStreamSynchronize(b.st));
-            (void)hipFree(part);
             rc = leann_scan_topk_device(h->g.X, n, h->g.d, h->g.ld, mean, 1, 1, nullptr, 0, mk, ms, mc, b.st);
             if (rc) return rc;
             uint64_t key = 0;
             BCHECK(hipMemcpyAsync(&key, mk, 8, hipMemcpyDeviceToHost, b.st));
             BCHECK(hipStreamSynchronize(b.st));
             first = (uint32_t)key;
-            (void)hipFree(mean); (void)hipFree(mk); (void)hipFree(ms); (void)hipFree(mc);
         }
         if (h->kind == LEANN_BACKEND_HNSW) first = insertion_order(b.order, 0, n);
         else insertion_order(b.order, 0, n, &first);
@@ -626,10 +633,7 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
     size_t bmax = bmax_hint ? bmax_hint : 16384;
     rc = builder_alloc_scratch(b, bmax);
     if (rc == LEANN_OK) rc = builder_insert_range(b, {}, s0, n);
-    (void)hipStreamSynchronize(b.st);
-    builder_free_scratch(b);
-    (void)hipStreamDestroy(b.st);
-    return rc;
+    return rc; // ~Builder: stream synchronised, scratch freed
 }
 
 // levels / upper_off on host (orc_level twin: common.cuh:node_level), uploaded once
@@ -697,8 +701,14 @@ extern "C" int leann_backend_build_device(int backend, const float *d_vectors, s
     h->g.M0 = backend == LEANN_BACKEND_HNSW ? (uint32_t)(2 * graph_degree) : (uint32_t)graph_degree;
     if (take_copy) {
         float *cp = nullptr;
-        BCHECK(hipMalloc((void **)&cp, std::max<size_t>(n * ld, 4) * 4));
-        if (n) BCHECK(hipMemcpy(cp, d_vectors, n * ld * 4, hipMemcpyDeviceToDevice));
+        if (hipMalloc((void **)&cp, std::max<size_t>(n * ld, 4) * 4) != hipSuccess ||
+            (n && hipMemcpy(cp, d_vectors, n * ld * 4, hipMemcpyDeviceToDevice) != hipSuccess)) {
+            leann_set_error("build: copying %zu rows failed: %s", n, hipGetErrorString(hipGetLastError()));
+            (void)hipFree(cp);
+            h->owns_rows = false;
+            leann_backend_close(h);
+            return LEANN_ERR_DEVICE;
+        }
         h->g.X = cp;
         h->owns_rows = true;
     } else {
@@ -772,11 +782,14 @@ extern "C" int leann_backend_add(int backend, const float *vectors, size_t n, si
     // on a different batch schedule.
     const size_t ld = old->g.ld, nt = n_old + n;
     float *dX = nullptr;
-    BCHECK(hipMalloc((void **)&dX, std::max<size_t>(nt * ld, 4) * 4));
-    if (n_old) BCHECK(hipMemcpy(dX, old->g.X, n_old * ld * 4, hipMemcpyDeviceToDevice));
-    if (n) {
-        BCHECK(hipMemset(dX + n_old * ld, 0, n * ld * 4));
-        BCHECK(hipMemcpy2D(dX + n_old * ld, ld * 4, vectors, dims * 4, dims * 4, n, hipMemcpyHostToDevice));
+    if (hipMalloc((void **)&dX, std::max<size_t>(nt * ld, 4) * 4) != hipSuccess ||
+        (n_old && hipMemcpy(dX, old->g.X, n_old * ld * 4, hipMemcpyDeviceToDevice) != hipSuccess) ||
+        (n && (hipMemset(dX + n_old * ld, 0, n * ld * 4) != hipSuccess ||
+               hipMemcpy2D(dX + n_old * ld, ld * 4, vectors, dims * 4, dims * 4, n, hipMemcpyHostToDevice) != hipSuccess))) {
+        leann_set_error("add_to_index: staging %zu rows on the device failed: %s", nt, hipGetErrorString(hipGetLastError()));
+        (void)hipFree(dX);
+        leann_backend_close(old);
+        return LEANN_ERR_DEVICE;
     }
     leann_backend *h = new leann_backend();
     h->kind = backend;

@@ -3,6 +3,7 @@
 #include "search.cuh"
 #include "../../include/leann_backend.h"
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -30,15 +31,28 @@ struct leann_backend {
     std::mutex mu;
     std::vector<Workspace *> free_ws; // host-pointer API: one per concurrent caller
     // pooled HBM visited tables (search.cuh): shared by every stream, handed out by in-kernel locks
-    unsigned long long *gpool = nullptr;
-    uint32_t *gpool_lock = nullptr, *gpool_ctr = nullptr;
+    unsigned long long *gpool = nullptr, *gpool2 = nullptr;
+    uint32_t *gpool_lock = nullptr, *gpool_ctr = nullptr, *gpool2_lock = nullptr;
+    uint32_t gpool_bits = GPOOL_BITS, gpool_tables = GPOOL_TABLES, gpool2_bits = 0, gpool2_tables = 0;
     leann_search_stats stats{};
     // recompute-on graph mode (g.feat_h != 0): encoder weights as f32 [feat_h x dims] for the query projection and
     // per-stream scratch for the projected queries
     float *Wf32 = nullptr;
     std::map<hipStream_t, std::pair<float *, size_t>> proj_scratch;
-    Coalescer *coalescer = nullptr; // optional request coalescing for single-query callers (api.hip)
+    std::shared_ptr<Coalescer> coalescer; // optional request coalescing for single-query callers (api.hip); swapped under `mu`
 };
+
+// LEANN_LOG=error|warn|info|debug (default warn) -> stderr, "LEVEL leann_hip: message" (the reference logs through tracing, cli/mod.rs:38-43)
+enum { LEANN_LOG_ERROR = 0, LEANN_LOG_WARN = 1, LEANN_LOG_INFO = 2, LEANN_LOG_DEBUG = 3 };
+void leann_log(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// host-side graph arrays -> device index; exactly one of `vectors` (f32 rows [n x dims]) and `feat_rows` (recompute-on rows
+// [n x row_bytes] + Wf32 [feat_h x dims]) is given.  Validates every array against n before anything is uploaded.
+int leann_internal_from_host(int backend, size_t n, size_t dims, uint32_t M, uint32_t M0, uint32_t max_level, uint32_t entry,
+                             const uint8_t *levels, const uint32_t *upper_off, const uint32_t *adj0, const uint32_t *adjU,
+                             size_t n_upper_lists, const float *vectors, const unsigned char *feat_rows, uint32_t feat_h, uint32_t row_bytes,
+                             const float *Wf32, int device, uint64_t key_offset, leann_backend **out);
+int leann_internal_save_to(const leann_backend *h, const std::string &path);
+int leann_internal_parse_device(const char *spec, int *device);
 
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st);
 
@@ -60,3 +74,4 @@ int leann_internal_score(const float *X, size_t rows, size_t dims, size_t ld, co
                          hipStream_t st);
 void leann_internal_free_graph(leann_backend *h);
 std::string leann_internal_index_file(const char *stem, int backend);
+std::string leann_internal_with_extension(const std::string &stem, const char *ext);

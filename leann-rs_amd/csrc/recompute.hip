@@ -790,7 +790,12 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     HIP_CHECK_RET(hipMemsetAsync(best, 0xFF, sizeof(uint64_t) * nq * k, st));
     int rc = LEANN_OK;
     const size_t n_tiles = (nq + QT - 1) / QT;
-    std::vector<hipEvent_t> evs(n_tiles * n_chunks * 3 + 1);
+    struct EventSet { // destroyed on every exit, including the HIP_CHECK_RET returns below
+        std::vector<hipEvent_t> v;
+        ~EventSet() { for (auto &e : v) if (e) (void)hipEventDestroy(e); }
+    } evset;
+    evset.v.assign(n_tiles * n_chunks * 3 + 1, nullptr);
+    std::vector<hipEvent_t> &evs = evset.v;
     for (auto &e : evs) HIP_CHECK_RET(hipEventCreate(&e));
     size_t ei = 0;
     for (size_t q0 = 0; q0 < nq && rc == LEANN_OK; q0 += QT) {
@@ -838,7 +843,6 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
         }
         if (ei >= 3 && rc == LEANN_OK && hipEventElapsedTime(&ms, evs[ei - 1], evs[ei]) == hipSuccess) rw->last_ms[2] += ms;
     }
-    for (auto &e : evs) (void)hipEventDestroy(e);
     return rc;
 }
 

@@ -36,10 +36,13 @@ struct GraphView {
     uint32_t feat_h, row_bytes;
 };
 
-// Pool of visited tables in HBM for the rare query whose LDS table fills up: GPOOL_TABLES tables of
+// Pools of visited tables in HBM for the rare query whose LDS table fills up.  Pool 1: GPOOL_TABLES tables of
 // 2^GPOOL_BITS u64 slots {generation:32 | id:32}.  Never cleared: a slot whose generation differs
 // from the owner's current one is empty.  Only atomics touch it, so hand-over between workgroups
-// on different XCDs needs no fence.
+// on different XCDs needs no fence.  A query that fills even its pool-1 table (> 49 152 nodes visited on one level:
+// beams of ~1 000 and more) moves on to pool 2: a few tables sized by the host to hold EVERY node of the index at 75 % load
+// (api.hip:ensure_gpool), so a search can never run out of visited-set space; the `aborted` exit below is a defensive path
+// (reported as stat 3 and turned into LEANN_ERR_OVERFLOW by the host entry points; reachable only through the debug knobs).
 #define GPOOL_TABLES 1024u
 #define GPOOL_BITS 16u
 
@@ -52,13 +55,17 @@ struct SearchArgs {
     uint64_t *out_keys;       // [nq x k]
     float *out_dists;         // [nq x k]
     uint32_t *out_counts;     // [nq]
-    uint32_t *out_stats;      // [nq x 4] evals, hops0, hopsU, 1 if the HBM table was used  (optional)
+    uint32_t *out_stats;      // [nq x 4] evals, hops0, hopsU, visited-set level (0 LDS, 1 / 2 HBM pool, 3 = overflowed: empty result)  (optional)
     uint64_t *out_expanded;   // optional [nq x exp_cap]: (orderable(dist) << 32 | id) of every node expanded on the
     uint32_t *out_nexp;       //          target level, in expansion order (Vamana's visited set V), and its count
     uint32_t exp_cap;
-    unsigned long long *gpool; // [GPOOL_TABLES << GPOOL_BITS]
-    uint32_t *gpool_lock;     // [GPOOL_TABLES] 0 = free
-    uint32_t *gpool_ctr;      // [0] acquire ticket, [1] generation counter
+    unsigned long long *gpool; // [gpool_tables << gpool_bits]
+    uint32_t *gpool_lock;     // [gpool_tables] 0 = free
+    uint32_t *gpool_ctr;      // [0] acquire ticket (pool 1), [1] generation counter, [2] acquire ticket (pool 2)
+    uint32_t gpool_bits, gpool_tables;
+    unsigned long long *gpool2; // second-level pool (null: the index is small enough for pool 1 to hold all of it)
+    uint32_t *gpool2_lock;
+    uint32_t gpool2_bits, gpool2_tables;
     const uint8_t *allow;     // filtered kernels only: bitmap over local positions (bit i of byte i >> 3) ...
     uint64_t allow_stride;    // ... of query i at allow + i * allow_stride (0: one bitmap shared by the batch)
 };
@@ -77,9 +84,9 @@ __device__ __forceinline__ bool vis_insert_lds(uint32_t *tab, uint32_t bits, uin
         h = (h + 1) & mask;
     }
 }
-__device__ __forceinline__ bool vis_insert_hbm(unsigned long long *tab, uint32_t gen, uint32_t id) {
-    const uint32_t mask = (1u << GPOOL_BITS) - 1u;
-    uint32_t h = vis_hash(id, GPOOL_BITS);
+__device__ __forceinline__ bool vis_insert_hbm(unsigned long long *tab, uint32_t bits, uint32_t gen, uint32_t id) {
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t h = vis_hash(id, bits);
     const unsigned long long mine = ((unsigned long long)gen << 32) | id;
     for (;;) {
         unsigned long long cur = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -194,9 +201,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     uint32_t *table = reinterpret_cast<uint32_t *>(smem + off);
     const uint32_t hbits = a.hash_bits, hsize = 1u << hbits;
     uint32_t vis_limit = hsize - (hsize >> 2); // 75 % load
-    bool hbm = false;                 // visited set lives in the HBM pool table (after an overflow)
+    uint32_t hbm = 0;                 // 0: visited set in LDS; 1 / 2: in a pool-1 / pool-2 table in HBM (after an overflow)
     unsigned long long *gtab = nullptr;
-    uint32_t gslot = 0, gen = 0;
+    uint32_t gslot = 0, gen = 0, gbits = 0;
 
     // ---- query into registers -----------------------------------------------------------------
     float4 q[T];
@@ -237,7 +244,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
             if (hbm) {
                 gen = atomicAdd(&a.gpool_ctr[1], 1u) + 1u;
                 s.misc[5] = gen;
-                vis_insert_hbm(gtab, gen, key_id(best));
+                vis_insert_hbm(gtab, gbits, gen, key_id(best));
             } else {
                 table[vis_hash(key_id(best), hbits)] = key_id(best);
             }
@@ -278,7 +285,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     for (uint32_t base = 0; base < deg; base += 64) {
                         uint32_t e = (base + lane < deg) ? adj[base + lane] : LEANN_EMPTY;
                         bool isnew = false;
-                        if (e != LEANN_EMPTY) isnew = hbm ? vis_insert_hbm(gtab, gen, e) : vis_insert_lds(table, hbits, e);
+                        if (e != LEANN_EMPTY) isnew = hbm ? vis_insert_hbm(gtab, gbits, gen, e) : vis_insert_lds(table, hbits, e);
                         unsigned long long m = __ballot(isnew);
                         uint32_t pos = n_new + __popcll(m & ((1ull << lane) - 1ull));
                         if (isnew) s.s_new[pos] = e;
@@ -305,30 +312,46 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
 #endif
             const uint32_t table_full = s.misc[3];
             if (table_full) {
-                if (hbm) { aborted = true; break; } // even the 2^16-slot HBM table is 75 % full
-                // LDS table full: move the visited set to a pooled HBM table and redo this hop
+                // Table full: move the visited set one level up (LDS -> pool 1 -> pool 2) and redo this hop.
+                const uint32_t next = hbm + 1;
+                if (next > 2 || (next == 2 && !a.gpool2)) { aborted = true; break; } // defensive: see the pool comment above
                 __syncthreads(); // every thread has read the flag before it is cleared
                 if (tid == 0) {
-                    uint32_t t = atomicAdd(&a.gpool_ctr[0], 1u), slot;
-                    for (uint32_t i = 0;; i++) {
-                        slot = (t + i) % GPOOL_TABLES;
-                        if (atomicCAS(&a.gpool_lock[slot], 0u, 1u) == 0u) break;
-                        if ((i % GPOOL_TABLES) == GPOOL_TABLES - 1) __builtin_amdgcn_s_sleep(32);
+                    uint32_t *locks = next == 1 ? a.gpool_lock : a.gpool2_lock;
+                    const uint32_t ntab = next == 1 ? a.gpool_tables : a.gpool2_tables;
+                    uint32_t t = atomicAdd(&a.gpool_ctr[next == 1 ? 0 : 2], 1u), slot;
+                    for (uint32_t i = 0;; i++) { // holders never wait for anything, so a table always comes free
+                        slot = (t + i) % ntab;
+                        if (atomicCAS(&locks[slot], 0u, 1u) == 0u) break;
+                        if ((i % ntab) == ntab - 1) __builtin_amdgcn_s_sleep(32);
                     }
                     s.misc[4] = slot;
-                    s.misc[5] = atomicAdd(&a.gpool_ctr[1], 1u) + 1u;
+                    if (!hbm) s.misc[5] = atomicAdd(&a.gpool_ctr[1], 1u) + 1u; // pool 1 -> 2 keeps the generation
                     s.misc[3] = 0;
                 }
                 __syncthreads();
-                gslot = s.misc[4];
-                gen = s.misc[5];
-                gtab = a.gpool + ((size_t)gslot << GPOOL_BITS);
-                for (uint32_t i = tid; i < hsize; i += NW * 64) {
-                    uint32_t e = table[i];
-                    if (e != LEANN_EMPTY) vis_insert_hbm(gtab, gen, e);
+                const uint32_t nslot = s.misc[4];
+                const uint32_t nbits = next == 1 ? a.gpool_bits : a.gpool2_bits;
+                unsigned long long *ntab_p = (next == 1 ? a.gpool : a.gpool2) + ((size_t)nslot << nbits);
+                if (!hbm) {
+                    gen = s.misc[5];
+                    for (uint32_t i = tid; i < hsize; i += NW * 64) {
+                        uint32_t e = table[i];
+                        if (e != LEANN_EMPTY) vis_insert_hbm(ntab_p, nbits, gen, e);
+                    }
+                } else {
+                    for (uint32_t i = tid; i < (1u << gbits); i += NW * 64) {
+                        const unsigned long long cur = __hip_atomic_load(&gtab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)(cur >> 32) == gen) vis_insert_hbm(ntab_p, nbits, gen, (uint32_t)cur);
+                    }
+                    __syncthreads(); // every probe of the old table has returned
+                    if (tid == 0) atomicExch(&a.gpool_lock[gslot], 0u);
                 }
-                hbm = true;
-                vis_limit = (1u << GPOOL_BITS) - (1u << (GPOOL_BITS - 2));
+                gtab = ntab_p;
+                gbits = nbits;
+                gslot = nslot;
+                hbm = next;
+                vis_limit = (1u << gbits) - (1u << (gbits - 2));
                 __syncthreads();
                 continue;
             }
@@ -463,8 +486,8 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
 
     // ---- results ------------------------------------------------------------------------------
     __syncthreads();
-    if (hbm && tid == 0) atomicExch(&a.gpool_lock[gslot], 0u); // every probe of this workgroup has returned
-    if (aborted) { // pathological: > 49152 distinct nodes visited on one level; report an empty result
+    if (hbm && tid == 0) atomicExch(&(hbm == 1 ? a.gpool_lock : a.gpool2_lock)[gslot], 0u); // every probe of this workgroup has returned
+    if (aborted) { // defensive (see the pool comment): the last table level filled up; empty result + stat 3 -> LEANN_ERR_OVERFLOW
         for (uint32_t t = tid; t < a.k; t += NW * 64) {
             a.out_keys[(size_t)qi * a.k + t] = 0xFFFFFFFFFFFFFFFFull;
             a.out_dists[(size_t)qi * a.k + t] = __uint_as_float(0x7F800000u);
@@ -475,7 +498,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 a.out_stats[(size_t)qi * 4 + 0] = n_evals;
                 a.out_stats[(size_t)qi * 4 + 1] = hops0;
                 a.out_stats[(size_t)qi * 4 + 2] = hopsU;
-                a.out_stats[(size_t)qi * 4 + 3] = 2u;
+                a.out_stats[(size_t)qi * 4 + 3] = 3u;
             }
         }
         return;
@@ -506,7 +529,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
             a.out_stats[(size_t)qi * 4 + 0] = n_evals;
             a.out_stats[(size_t)qi * 4 + 1] = hops0;
             a.out_stats[(size_t)qi * 4 + 2] = hopsU;
-            a.out_stats[(size_t)qi * 4 + 3] = hbm ? 1u : 0u;
+            a.out_stats[(size_t)qi * 4 + 3] = hbm; // 0 LDS table only, 1 / 2 the visited set moved to pool 1 / 2
         }
     }
     __syncthreads();

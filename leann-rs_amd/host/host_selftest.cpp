@@ -62,6 +62,35 @@ int main(int argc, char **argv) {
         for (float f : synthetic_embed(in["synthetic_embed"].s, 16)) e.a->push_back(lj::Value::number((double)f));
         out["synthetic_embed"] = e;
     }
+    // IndexSearcher::search_with_options after the backend call, on recorded backend output:
+    //   {"index_path": ".../documents.leann", "cases": [{top_k, hybrid, alpha, filter, query_text, backend: [[key, dist], ...]}]}
+    if (in.get("searcher")) {
+        const lj::Value &sv = in["searcher"];
+        IndexSearcher searcher = IndexSearcher::load_passages_only(sv.get("index_path")->s);
+        lj::Value all = lj::Value::array();
+        for (auto &c : *sv.get("cases")->a) {
+            const size_t top_k = (size_t)c.get("top_k")->as_f64();
+            SearchOptions opts(top_k, 64);
+            const bool hybrid = c.get("hybrid") && c.get("hybrid")->b;
+            if (hybrid) opts.with_hybrid(c.get("query_text")->s, (float)c.get("alpha")->as_f64());
+            if (c.get("filter") && c.get("filter")->is_string()) {
+                auto f = MetadataFilter::parse(c.get("filter")->s);
+                if (f) opts.with_filter(*f);
+            }
+            const size_t fetch_k = (opts.filter || opts.hybrid) ? top_k * 5 : top_k;
+            std::vector<std::pair<size_t, float>> vr;
+            for (auto &p : *c.get("backend")->a) vr.emplace_back((size_t)(*p.a)[0].as_f64(), (float)(*p.a)[1].as_f64());
+            lj::Value res = lj::Value::array();
+            for (auto &r : searcher.assemble_results(vr, opts, fetch_k)) {
+                lj::Value e = lj::Value::array();
+                e.a->push_back(lj::Value::string(r.id));
+                e.a->push_back(lj::Value::number((double)r.score));
+                res.a->push_back(e);
+            }
+            all.a->push_back(res);
+        }
+        out["searcher"] = all;
+    }
     printf("%s\n", lj::to_string_pretty(out).c_str());
     return 0;
 }

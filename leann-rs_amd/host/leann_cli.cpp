@@ -130,7 +130,7 @@ static int run_search(int argc, char **argv) {
             memcpy(v.data(), raw.data(), raw.size());
             return v;
         }
-        if (mode != "synthetic") {
+        if (mode != "synthetic" && mode != "synthetic-linear") {
             if (mode == "openai" || mode == "ollama" || mode == "gemini")
                 throw Error("Embedding mode '" + mode + "' needs a network service that is unavailable in this build; "
                             "pass --embedding-mode synthetic or --query-vector-file");
@@ -140,13 +140,7 @@ static int run_search(int argc, char **argv) {
     };
 
     std::vector<SearchResult> results;
-    if (is_pruned) { // search.rs:151-167
-        auto q = embed_query(a.query);
-        if (mode != "synthetic") throw Error("recompute mode needs an embedding provider; only `synthetic` works offline");
-        EmbeddingProvider provider(mode, meta.dimensions);
-        RecomputeSearcher searcher = RecomputeSearcher::load(index_path, meta.dimensions);
-        results = searcher.search(q, provider, a.top_k, filter ? &*filter : nullptr);
-    } else {
+    auto graph_search = [&]() {
         IndexSearcher searcher = IndexSearcher::load(index_path, meta, a.device.c_str());
         // query expansion (src/index/query.rs) is a text heuristic outside the scoped path: not applied
         auto q = embed_query(a.query);
@@ -155,6 +149,29 @@ static int run_search(int argc, char **argv) {
         if (filter && a.device_filter) opts.with_device_filter(*a.filter);
         if (use_hybrid) opts.with_hybrid(a.query, a.hybrid_alpha);
         results = searcher.search_with_options(q, opts);
+    };
+    // A pruned index (search.rs:151-167) recomputes embeddings at query time.  The reference scans every passage through the provider
+    // (RecomputeSearcher).  When the directory holds a recompute-on GRAPH (`leann build --recompute-graph`: our file format version 2 —
+    // graph + compact encoder inputs, no vectors) the graph is walked instead and distances are recomputed on the device per visited node.
+    const std::string ann_file = with_extension(index_path, meta.backend_name == "diskann" ? "diskann" : "index");
+    bool pruned_graph = false;
+    if (is_pruned && file_exists(ann_file)) {
+        std::ifstream f(ann_file, std::ios::binary);
+        char hd[16] = {0};
+        f.read(hd, 16);
+        uint32_t version = 0;
+        memcpy(&version, hd + 8, 4);
+        pruned_graph = f.gcount() == 16 && !memcmp(hd, "LEANNGX1", 8) && version == 2;
+    }
+    if (is_pruned && !pruned_graph) {
+        auto q = embed_query(a.query);
+        if (mode != "synthetic" && mode != "synthetic-linear")
+            throw Error("recompute mode needs an embedding provider; only `synthetic` / `synthetic-linear` work offline");
+        EmbeddingProvider provider(mode, meta.dimensions);
+        RecomputeSearcher searcher = RecomputeSearcher::load(index_path, meta.dimensions);
+        results = searcher.search(q, provider, a.top_k, filter ? &*filter : nullptr);
+    } else {
+        graph_search();
     }
 
     if (a.format == "json") { // search.rs:211-223
@@ -192,11 +209,15 @@ static int run_search(int argc, char **argv) {
 }
 
 // leann build --index-dir DIR --passages-jsonl FILE [--backend-name hnsw|diskann] [--graph-degree 32]
-//             [--complexity 64] [--dimensions 128] [--pruned]
+//             [--complexity 64] [--dimensions 128] [--embedding-mode synthetic|synthetic-linear] [--recompute] [--pruned]
+//             [--recompute-graph]
+// --recompute       also write documents.embeddings (src/index/builder.rs:105-113), so that the index can be pruned later
+// --pruned          no ANN file and no embeddings: the reference's pruned state (brute-force recompute at query time)
+// --recompute-graph (needs --embedding-mode synthetic-linear) graph + compact encoder inputs, no vectors
 static int run_build(int argc, char **argv) {
-    std::string dir, jsonl, backend_name = "hnsw";
+    std::string dir, jsonl, backend_name = "hnsw", mode = "synthetic";
     size_t degree = 32, complexity = 64, dims = 128;
-    bool pruned = false;
+    bool pruned = false, recompute = true, rgraph = false;
     for (int i = 0; i < argc; i++) {
         std::string s = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) throw Error("missing value for " + s); return argv[++i]; };
@@ -206,18 +227,23 @@ static int run_build(int argc, char **argv) {
         else if (s == "--graph-degree") degree = std::stoul(val());
         else if (s == "--complexity") complexity = std::stoul(val());
         else if (s == "--dimensions") dims = std::stoul(val());
+        else if (s == "--embedding-mode") mode = val();
         else if (s == "--pruned") pruned = true;
+        else if (s == "--recompute") recompute = true;
+        else if (s == "--recompute-graph") { rgraph = true; mode = "synthetic-linear"; }
         else throw Error("unexpected argument '" + s + "' found");
     }
     if (dir.empty() || jsonl.empty()) throw Error("usage: leann build --index-dir DIR --passages-jsonl FILE [...]");
     int backend = backend_name == "hnsw" ? LEANN_BACKEND_HNSW : backend_name == "diskann" ? LEANN_BACKEND_DISKANN : -1;
     if (backend < 0) throw Error("Unknown backend: " + backend_name);
+    EmbeddingProvider provider(mode, dims);
     ::mkdir(dir.c_str(), 0755);
     std::string stem = dir + "/documents.leann";
     std::ifstream in(jsonl);
     if (!in) throw Error("cannot open " + jsonl);
     PassageStoreWriter w(stem);
     std::vector<float> all;
+    std::vector<uint16_t> feats;
     std::ofstream ids(with_extension(stem, "ids.txt"));
     size_t n = 0;
     for (std::string line; std::getline(in, line);) {
@@ -229,28 +255,51 @@ static int run_build(int argc, char **argv) {
         p.metadata = v.get("metadata") ? *v.get("metadata") : lj::Value::object();
         w.add(p);
         ids << p.id << "\n";
-        auto e = synthetic_embed(p.text, dims);
-        all.insert(all.end(), e.begin(), e.end());
+        if (rgraph) {
+            auto f = linear_features(p.text);
+            feats.insert(feats.end(), f.begin(), f.end());
+        } else if (!pruned) {
+            auto e = provider.embed({p.text})[0];
+            all.insert(all.end(), e.begin(), e.end());
+        }
         n++;
     }
     w.finish();
     ids.close();
-    if (!pruned) { // src/index/embeddings.rs: raw LE f32 [n x dims]
-        std::ofstream ef(with_extension(stem, "embeddings"), std::ios::binary);
-        ef.write((const char *)all.data(), (std::streamsize)(all.size() * 4));
+    if (rgraph) {
+        // the embeddings exist only transiently on the device while the graph is built (leann_recompute_build_index)
+        leann_recompute *r = nullptr;
+        check(leann_recompute_create_host(feats.data(), n, LINEAR_H, provider.weights().data(), dims, 0, 0, &r));
+        leann_backend *h = nullptr;
+        int rc = leann_recompute_build_index(r, backend, degree, complexity, &h);
+        if (rc == 0) rc = leann_backend_save(h, stem.c_str());
+        if (h) leann_backend_close(h);
+        leann_recompute_close(r);
+        check(rc);
+    } else if (!pruned) {
+        if (recompute) { // src/index/embeddings.rs: raw LE f32 [n x dims]
+            std::ofstream ef(with_extension(stem, "embeddings"), std::ios::binary);
+            ef.write((const char *)all.data(), (std::streamsize)(all.size() * 4));
+        }
         check(leann_backend_build(backend, all.data(), n, dims, degree, complexity, stem.c_str()));
     }
     IndexMeta m;
     m.version = "1.0";
     m.backend_name = backend_name;
-    m.embedding_model = "synthetic-hash";
-    m.embedding_mode = "synthetic";
+    m.embedding_model = mode == "synthetic" ? "synthetic-hash" : "synthetic-linear-256";
+    m.embedding_mode = mode;
     m.dimensions = dims;
     m.passage_count = n;
-    m.is_recompute = pruned;
-    m.is_pruned = pruned;
+    m.is_recompute = pruned || rgraph || recompute;
+    m.is_pruned = pruned || rgraph;
+    if (rgraph) {
+        m.backend_kwargs = lj::Value::object();
+        m.backend_kwargs["recompute_graph"] = lj::Value::boolean(true);
+        m.backend_kwargs["feature_dim"] = lj::Value::integer((int64_t)LINEAR_H);
+    }
     m.save(dir + "/documents.leann.meta.json");
-    printf("Indexed %zu passages (%zu dims, backend %s%s) into %s\n", n, dims, backend_name.c_str(), pruned ? ", pruned" : "", dir.c_str());
+    printf("Indexed %zu passages (%zu dims, backend %s%s) into %s\n", n, dims, backend_name.c_str(),
+           rgraph ? ", recompute-on graph (no vectors)" : pruned ? ", pruned" : "", dir.c_str());
     return 0;
 }
 

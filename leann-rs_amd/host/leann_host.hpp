@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <limits>
 #include <map>
@@ -481,6 +482,13 @@ class IndexSearcher {
         s.backend_.reset(h, leann_backend_close);
         return s;
     }
+    // passages + id map only, no backend: assemble_results on recorded backend output (CPU tests)
+    static IndexSearcher load_passages_only(const std::string &index_path) {
+        IndexSearcher s;
+        s.passages_ = PassageStore::open(index_path);
+        s.id_map_ = read_id_map(index_path, s.passages_);
+        return s;
+    }
     std::vector<SearchResult> search(const std::vector<float> &q, size_t top_k, size_t complexity) const {
         return search_with_options(q, SearchOptions(top_k, complexity));
     }
@@ -518,6 +526,12 @@ class IndexSearcher {
         }
         std::vector<std::pair<size_t, float>> vector_results;
         for (size_t i = 0; i < n; i++) vector_results.emplace_back((size_t)keys[i], dists[i]); // score = backend distance (N1)
+        return assemble_results(std::move(vector_results), opts, fetch_k);
+    }
+    // Everything of search_with_options after the backend call (:146-207): hybrid merge, id map, passage fetch, post-filter, top_k cut.
+    // Public so that the CPU suite can drive it with recorded backend output (tests/golden/searcher_cases.json, host_selftest).
+    std::vector<SearchResult> assemble_results(std::vector<std::pair<size_t, float>> vector_results, const SearchOptions &opts,
+                                               size_t fetch_k) const {
         if (opts.hybrid && opts.query_text) { // :146-169
             // The reference re-reads every passage and rebuilds the BM25 tables per query (:149-151, :213-224);
             // the index is immutable while open, so the tables are built once and kept —
@@ -637,16 +651,77 @@ inline std::vector<float> synthetic_embed(const std::string &text, size_t dims) 
     for (float &x : v) x /= nrm;
     return v;
 }
+// "synthetic-linear": the recompute path's device-resident provider fed from text — compact per-passage features
+// + a dense layer + L2 normalisation (the tail of a real encoder, candle.rs:165,218-225):
+//     f = signed hashed bag of tokens [LINEAR_H]  (small integers: exact in bf16),   W [LINEAR_H x dims] bf16, seeded Gaussian,
+//     embedding = l2_normalize(W^T f).
+// An index built with `--recompute-graph` stores the graph and the features (520 B per passage), never the embeddings; the host
+// only embeds the QUERY text (this function), distances are recomputed on the device during the walk.
+constexpr size_t LINEAR_H = 256;
+inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline std::vector<uint16_t> linear_features(const std::string &text) {
+    std::vector<float> f(LINEAR_H, 0.0f);
+    auto toks = tokenize(text);
+    if (toks.empty()) toks.push_back(text);
+    for (auto &t : toks) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (unsigned char c : t) h = (h ^ c) * 0x100000001b3ull;
+        for (int rep = 0; rep < 4; rep++) { // four signed buckets per token: fewer collisions between distinct tokens
+            const uint64_t r = mix64(h + (uint64_t)rep * 0x9E3779B97F4A7C15ull);
+            f[r % LINEAR_H] += (r >> 63) ? 1.0f : -1.0f;
+        }
+    }
+    std::vector<uint16_t> out(LINEAR_H);
+    for (size_t k = 0; k < LINEAR_H; k++) out[k] = bf16_rne(f[k]);
+    return out;
+}
+inline std::vector<uint16_t> linear_weights(size_t dims) { // [LINEAR_H x dims] bf16, row-major
+    std::vector<uint16_t> W(LINEAR_H * dims);
+    for (size_t k = 0; k < LINEAR_H; k++)
+        for (size_t j = 0; j < dims; j++) {
+            const uint64_t r = mix64(mix64(0x4C494E454152ull ^ (k * 0xD1342543DE82EF95ull)) ^ (j * 0xA24BAED4963EE407ull));
+            const int32_t sgn = (int32_t)((r & 0xFFFF) + ((r >> 16) & 0xFFFF) + ((r >> 32) & 0xFFFF) + (r >> 48));
+            W[k * dims + j] = bf16_rne((float)(sgn - 131070) * 2.6428996e-05f);
+        }
+    return W;
+}
+inline std::vector<float> linear_embed(const std::string &text, const std::vector<uint16_t> &W, size_t dims) {
+    const auto f = linear_features(text);
+    std::vector<float> e(dims, 0.0f);
+    for (size_t k = 0; k < LINEAR_H; k++) {
+        const float fk = bf16_to_f32(f[k]);
+        if (fk == 0.0f) continue;
+        for (size_t j = 0; j < dims; j++) e[j] = std::fma(bf16_to_f32(W[k * dims + j]), fk, e[j]);
+    }
+    float ss = 0.0f;
+    for (float x : e) ss += x * x;
+    float nrm = std::sqrt(ss);
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    for (float &x : e) x /= nrm;
+    return e;
+}
+
 class EmbeddingProvider {
   public:
     EmbeddingProvider(std::string mode, size_t dims) : mode_(std::move(mode)), dims_(dims) {
-        if (mode_ != "synthetic")
+        if (mode_ != "synthetic" && mode_ != "synthetic-linear")
             throw Error("Embedding mode '" + mode_ + "' needs a network service that is unavailable in this build; "
                         "use --embedding-mode synthetic or --query-vector-file");
+        if (mode_ == "synthetic-linear") weights_ = linear_weights(dims_);
     }
     std::vector<std::vector<float>> embed(const std::vector<std::string> &texts) const {
         std::vector<std::vector<float>> out;
-        for (auto &t : texts) out.push_back(synthetic_embed(t, dims_));
+        for (auto &t : texts) out.push_back(weights_.empty() ? synthetic_embed(t, dims_) : linear_embed(t, weights_, dims_));
         return out;
     }
     std::vector<std::vector<float>> embed_with_template(const std::vector<std::string> &texts, const std::string &tmpl) const {
@@ -655,10 +730,12 @@ class EmbeddingProvider {
         return embed(t2);
     }
     size_t dimensions() const { return dims_; }
+    const std::vector<uint16_t> &weights() const { return weights_; } // synthetic-linear: W [LINEAR_H x dims] bf16
 
   private:
     std::string mode_;
     size_t dims_;
+    std::vector<uint16_t> weights_;
 };
 
 // ---- src/index/recompute.rs ---------------------------------------------------------------------------

@@ -8,7 +8,8 @@ Follows src/index/bm25.rs line by line in numpy float32 scalars (pure-Python loo
     search           bm25.rs:109-122   positives only, stable sort descending, truncate
 hybrid_rerank (bm25.rs:135-170) lives in oracle.c (orc_hybrid_rerank).
 """
-import math
+import ctypes
+import ctypes.util
 import re
 
 import numpy as np
@@ -17,6 +18,14 @@ f32 = np.float32
 K1 = f32(1.2)
 B = f32(0.75)
 _TOKEN = re.compile(r"[a-zA-Z0-9]+")
+# f32::ln is the platform libm's logf (what the C++ host's std::log(float) calls too): bit-identical, unlike log(double) rounded
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.logf.restype = ctypes.c_float
+_libm.logf.argtypes = [ctypes.c_float]
+
+
+def logf(x):
+    return f32(_libm.logf(float(x)))
 
 
 def tokenize(text):
@@ -53,7 +62,7 @@ class Bm25Scorer:
             if df == 0:
                 continue
             ratio = f32(f32(f32(self.num_docs) - df) + f32(0.5)) / f32(df + f32(0.5))
-            idf = f32(math.log(f32(ratio + f32(1.0))))
+            idf = logf(f32(ratio + f32(1.0)))
             for doc_id, tfm in enumerate(self.term_freqs):
                 tf = f32(tfm.get(token, 0))
                 if tf == 0:

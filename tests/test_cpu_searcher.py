@@ -1,0 +1,88 @@
+"""CPU suite: IndexSearcher::search_with_options (src/index/searcher.rs:123-210) after the backend call — the C++ host's
+assemble_results and the Python restatement (oracle/searcher_oracle.py) against tests/golden/searcher_cases.json: recorded backend
+outputs -> expected (id, f32 score) lists.  Bit-exact scores.  The index directory is written here in the reference's layout
+(passages.rs:48-49,120-158; searcher.rs:83), so the C++ readers are exercised on files they did not write.  No GPU."""
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "leann-rs_amd", "host")
+FX = json.load(open(os.path.join(ROOT, "tests", "golden", "searcher_cases.json")))
+f32 = np.float32
+
+
+def write_reference_layout(d, docs, with_ids=True):
+    """documents.passages.jsonl + .passages.idx.json (+ documents.ids.txt) exactly as the reference's PassageStoreWriter does"""
+    os.makedirs(d, exist_ok=True)
+    offsets, pos = {}, 0
+    with open(os.path.join(d, "documents.passages.jsonl"), "wb") as f:
+        for p in docs:
+            line = (json.dumps(dict(id=p["id"], text=p["text"], metadata=p["metadata"])) + "\n").encode()
+            offsets[p["id"]] = pos
+            f.write(line)
+            pos += len(line)
+    json.dump(offsets, open(os.path.join(d, "documents.passages.idx.json"), "w"))
+    if with_ids:
+        open(os.path.join(d, "documents.ids.txt"), "w").write("".join(p["id"] + "\n" for p in docs))
+    return os.path.join(d, "documents.leann")
+
+
+def test_python_restatement_reproduces_the_fixture(po):
+    import searcher_oracle as so
+    docs = FX["corpus"]
+    id_map = [d["id"] for d in docs]
+    passages = {d["id"]: d for d in docs}
+    for c in FX["cases"]:
+        rec = c["backend"]
+        res = so.search_with_options(lambda q, fk, cx: ([k for k, _ in rec], [f32(d) for _, d in rec]), id_map, passages, None,
+                                     c["top_k"], 64, filter_text=c.get("filter"), hybrid=c.get("hybrid", False),
+                                     hybrid_alpha=c.get("alpha", 0.7), query_text=c.get("query_text"))
+        assert [(i, f32(s)) for i, s in res] == [(i, f32(s)) for i, s in c["expect"]], c["name"]
+
+
+def test_hybrid_rerank_restatements_agree(po):
+    """searcher_oracle.hybrid_rerank (numpy f32) == oracle.c:orc_hybrid_rerank on the fixture's hybrid cases"""
+    import bm25_oracle as bo
+    import searcher_oracle as so
+    docs = FX["corpus"]
+    scorer = bo.Bm25Scorer.build([d["text"] for d in docs])
+    for c in FX["cases"]:
+        if not c.get("hybrid") or not c["backend"]:
+            continue
+        vr = [(k, f32(d)) for k, d in c["backend"] if k < len(docs)]
+        bm = scorer.score_query(c["query_text"])
+        a = so.hybrid_rerank(vr, bm, c["alpha"])
+        b = po.hybrid_rerank([(k, float(d)) for k, d in vr], bm, c["alpha"])
+        assert [(i, f32(s)) for i, s in a] == [(i, f32(s)) for i, s in b], c["name"]
+
+
+def test_semantics_the_fixture_pins():
+    by = {c["name"]: c for c in FX["cases"]}
+    # keys beyond the id map become their decimal string (searcher.rs:180-184); no such passage -> skipped (:203-205)
+    assert len(by["plain_key_beyond_id_map"]["expect"]) == 3
+    # post-filter on a 5x over-fetch can starve (searcher.rs:129-133,:190-194)
+    assert len(by["filter_starved"]["expect"]) < by["filter_starved"]["top_k"]
+    # BM25-only hits enter with vector score 0.0 (:160-165): with an empty backend answer every blended score is (1-alpha)*norm_bm25
+    assert all(abs(s - 0.3) < 1e-6 or s < 0.3 for _, s in by["hybrid_empty_backend"]["expect"])
+    # polarity quirk N1: the WORST distance of the backend list gets norm_vec = 1 -> with no BM25 match the order is reversed
+    c = by["hybrid_no_bm25_match"]
+    worst_first = [str(k + 1) for k, _ in sorted(c["backend"], key=lambda t: -t[1])][:3]
+    assert [i for i, _ in c["expect"]] == worst_first
+
+
+def test_cpp_assemble_results_matches_the_fixture(tmp_path):
+    exe = os.path.join(HOST, "host_selftest")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", ROOT, "leann-rs_amd/host/host_selftest"])
+    stem = write_reference_layout(str(tmp_path / "idx"), FX["corpus"])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_formulas.json")))
+    cases = dict(tokenize=gold["tokenize"], bm25=gold["bm25"], hybrid_rerank=gold["hybrid_rerank"],
+                 searcher=dict(index_path=stem, cases=FX["cases"]))
+    p = tmp_path / "cases.json"
+    p.write_text(json.dumps(cases))
+    out = json.loads(subprocess.check_output([exe, str(p)]))
+    for c, got in zip(FX["cases"], out["searcher"]):
+        assert [(i, f32(s)) for i, s in got] == [(i, f32(s)) for i, s in c["expect"]], c["name"]

@@ -27,3 +27,21 @@ def traced_graph():
     adj0 = np.array(fx["adj0"], np.uint32)
     adjU = np.array(fx["adjU"], np.uint32)
     return fx, X, levels, upper_off, adj0, adjU
+
+
+def write_gx1(path, kind, X, M, M0, max_level, entry, levels, upper_off, adj0, adjU, efc=64, alpha=1.2):
+    """a version-1 LEANNGX1 index file (csrc/indexfile.hip) written from numpy arrays; returns the header bytes"""
+    import struct
+    X = np.ascontiguousarray(X, np.float32)
+    n, d = X.shape
+    adjU = np.ascontiguousarray(adjU, np.uint32).reshape(-1, M) if np.size(adjU) else np.zeros((0, M), np.uint32)
+    hd = struct.pack("<8sIIQIIIIIIfIQI60x", b"LEANNGX1", 1, kind, n, d, M, M0, max_level, entry, efc, alpha, 0, adjU.shape[0], 0)
+    assert len(hd) == 128
+    with open(path, "wb") as f:
+        f.write(hd)
+        f.write(np.ascontiguousarray(levels, np.uint8).tobytes())
+        f.write(np.ascontiguousarray(upper_off, np.uint32).tobytes())
+        f.write(np.ascontiguousarray(adj0, np.uint32).tobytes())
+        f.write(adjU.tobytes())
+        f.write(X.tobytes())
+    return hd
