@@ -11,10 +11,13 @@ Inputs (corpus rows, graph, queries) are resident in HBM before the timed region
 N > 1 (launched by torch.distributed.run, one rank per GPU):
   mode shard   (default, north_star): the corpus is partitioned, every rank holds `rows` vectors
                (weak scaling: corpus = N x rows) with its own graph, all ranks search the same query
-               batch, per-shard top-k lists are all-gathered over RCCL and merged on every rank.
-               The unit a rank processes is one query searched against its `rows`-vector shard —
-               the same unit as at N = 1 — so value = N * batch * K / t; the end-to-end rate over
-               the whole N x rows corpus is reported beside it as "end_to_end_qps" (= value / N).
+               batch, per-shard top-k lists are all-gathered over RCCL and merged on every rank — all
+               of it inside the library (leann_sharded_attach / leann_sharded_search_batch_device_async,
+               csrc/shard.hip); torch only hands rank 0's RCCL id to the other ranks.
+               value = batch * K / t: END-TO-END queries/s over the whole N x rows corpus (every query
+               is answered once, by all shards together).  Weak scaling therefore means: the corpus
+               grows N-fold at (ideally) constant queries/s.  The per-shard search rate N * batch * K / t
+               rides along as "shard_searches_per_s".
   mode replica every rank holds the whole `rows`-vector index and takes different query batches;
                no data-path collective.
 """
@@ -126,6 +129,25 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
                 return hip_merge(gk, gs, gc, k, True, stream.cuda_stream)[0]
         return keys
 
+    # recall@10 measured in-run, not assumed: the reference's literal order — materialise every embedding (recompute.rs:86-93), then
+    # dot + sort + take (:96-109) — as leann_recompute_encode_device + leann_scan_topk_device over the same rows, against the fused search
+    recall, recall_note = None, "not measured (sharded / filtered run or too many rows to materialise)"
+    if not shard and allow is None and rows * ld * 4 <= 64 << 30:
+        E = torch.empty((rows, ld), dtype=torch.float32, device=dev)
+        for r0 in range(0, rows, 4 << 20):
+            chk(L.leann_recompute_encode_device(r, r0, min(4 << 20, rows - r0), E.data_ptr() + r0 * ld * 4, sp))
+        tk_, ts_, tc_ = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+                         torch.empty((B,), dtype=torch.int32, device=dev))
+        chk(L.leann_scan_topk_device(E.data_ptr(), rows, d, ld, Q.data_ptr(), B, k, None, 0, tk_.data_ptr(), ts_.data_ptr(), tc_.data_ptr(), sp))
+        step(0)
+        stream.synchronize()
+        a_, b_ = keys.cpu().numpy(), tk_.cpu().numpy()
+        recall = float(np.mean([len(set(a_[i].tolist()) & set(b_[i].tolist())) / k for i in range(B)]))
+        recall_note = (f"fused recompute search vs exact scan over the materialised embeddings of all {rows} passages, {B} queries "
+                       f"(max |score difference| {float((scores - ts_).abs().max()):.2e})")
+        del E
+        torch.cuda.empty_cache()
+        log("recall@%d = %.4f (%s)" % (k, recall, recall_note))
     for w in range(warmup):
         step(w)
     stream.synchronize()
@@ -158,9 +180,10 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
             "algorithmic_flops_per_step": enc_flops + 2.0 * rows * d * B,  # what the reference's order (embed, then d-dim dots) costs
             "algorithmic_bytes_per_step": rows * h * 2 + h * d * 2,
             "hbm_gbps_features": rows * h * 2 / (enc_ms * 1e-3) / 1e9}
-    out = {"metric": "queries/sec @ recall@10>=0.95", "value": B * steps * world / elapsed, "unit": "queries/s", "n_gpus": world,
+    # shard mode: every query is answered once by all shards together -> end-to-end queries/s = B * K / t
+    out = {"metric": "queries/sec @ recall@10>=0.95", "value": B * steps / elapsed, "unit": "queries/s", "n_gpus": world,
            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "bf16 encode / f32 score", "data": "synthetic", "recall_at_10": 1.0,
+           "vs_baseline": None, "dtype": "bf16 encode / f32 score", "data": "synthetic", "recall_at_10": recall, "recall_note": recall_note,
            "config": {"workload": f"{args.workload}: recompute-on (no stored vectors), {rows} passages x {h} bf16 features per GPU, "
                                   f"encoder W[{h}x{d}] bf16, embedding = l2norm(W^T f), batch {B} queries/step, exhaustive scan (exact)",
                       "rows_per_gpu": rows, "dims": d, "feature_dim": h, "batch": B, "top_k": k,
@@ -176,7 +199,7 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
         roof.update({"achieved": (e2 + s2) / (enc_ms * 1e-3) / 1e12, "frac": (e2 + s2) / (enc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                      "mfma_flops_per_step": e2 + s2, "kernel": "fused_fstat_kernel<16,false,true> (row list)"})
     if shard:
-        out["end_to_end_qps"] = B * steps / elapsed
+        out["shard_searches_per_s"] = B * steps * world / elapsed
     # ---- CPU baseline: the oracle's literal recompute.rs:86-109 (embed every passage, dot, sort) on a bounded sample -------
     if world == 1 and rank == 0 and not args.no_cpu_baseline and allow is None:
         try:
@@ -258,7 +281,7 @@ def bench_scan(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log):
     nbytes, flops = rows * d * 4.0, 2.0 * rows * d * B
     out = {"metric": "queries/sec @ recall@10>=0.95", "value": B * steps * world / elapsed, "unit": "queries/s", "n_gpus": world,
            "steps": steps, "warmup": warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic", "recall_at_10": 1.0,
+           "dtype": "f32", "data": "synthetic", "recall_at_10": 1.0, "recall_note": "this workload IS the exact scan (every other workload's ground truth)",
            "config": {"workload": f"{args.workload}: exact scan of {rows} x {d} stored f32 rows per GPU, batch {B} queries/step, top-{k}",
                       "rows_per_gpu": rows, "dims": d, "batch": B, "top_k": k, "parallelism": "single" if world == 1 else f"replica{world}"},
            # bit-exact f32 chains run on v_mfma_f32_32x32x2_f32: at batch 64 the matrix-core floor (flops / 157.3 TFLOP/s) is 1.6x the
@@ -312,6 +335,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency / 64-caller section")
     ap.add_argument("--cpu-queries", type=int, default=16384)
     ap.add_argument("--filter-selectivity", type=float, default=0.0,
                     help="side experiment (not the headline metric): metadata-filtered search with a seeded random allow-bitmap "
@@ -417,17 +441,25 @@ def main():
     else:
         with torch.cuda.stream(stream):
             chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 1, q_first, n_pool * B, Q.data_ptr(), sp))
-    # two sets of per-shard result buffers: with N > 1 the exchange + merge of step i runs on its own stream while the
+    # two sets of result buffers: with N > 1 the library runs the exchange + merge of step i on its own stream while the
     # traversal of step i + 1 fills the other set (the all-gather is latency-bound, so it is overlapped)
     kbuf = [torch.empty((B, k), dtype=torch.int64, device=dev) for _ in range(2)]
     dbuf = [torch.empty((B, k), dtype=torch.float32, device=dev) for _ in range(2)]
     cbuf = [torch.empty((B,), dtype=torch.int32, device=dev) for _ in range(2)]
     keys, dists, counts = kbuf[0], dbuf[0], cbuf[0]
     xstream = torch.cuda.Stream(device=dev)
-    ev_search = [torch.cuda.Event() for _ in range(2)]
-    ev_xdone = [None, None]
     stats = torch.zeros((n_pool, B, 4), dtype=torch.int32, device=dev)
     stream.synchronize()
+    group, tickets = None, [None, None]
+    rccl = shard and dist.get_backend() == "nccl"
+    if rccl:
+        # one RCCL communicator of the LIBRARY's own: local traversal, ncclAllGather of the packed per-shard block, merge kernel
+        # (csrc/shard.hip).  torch.distributed only carries the 128-byte id from rank 0 to the other ranks.
+        from leann_rs_amd.shard import rccl_group
+        group = rccl_group(searcher, corpus_total, world, rank)
+        log(f"rank {rank}: attached to the library's RCCL group ({group.n_shards()} shards, {group.len()} rows)")
+    ev_search = [torch.cuda.Event() for _ in range(2)]
+    ev_xdone = [None, None]
 
     allow = None
     if args.filter_selectivity > 0:
@@ -441,16 +473,22 @@ def main():
         torch.cuda.synchronize()
 
     def search(step, timed_events=None):
-        """one step of the hot path on `stream` (N > 1: + exchange and merge on `xstream`, overlapping the next step's traversal)"""
+        """one step of the hot path on `stream` (N > 1: + exchange and merge on the library's stream, overlapping the next step's traversal)"""
         qb = step % n_pool
         b = step & 1 if shard else 0
         keys, dists, counts = kbuf[b], dbuf[b], cbuf[b]
         qptr = Q.data_ptr() + qb * B * ld * 4
-        if shard and ev_xdone[b] is not None:
-            stream.wait_event(ev_xdone[b])  # the exchange that read this buffer set two steps ago
+        if rccl and tickets[b] is not None:
+            group.wait(tickets[b], sp)  # the exchange that wrote this buffer set two steps ago (at most two tickets may be outstanding)
+            tickets[b] = None
+        if shard and not rccl and ev_xdone[b] is not None:
+            stream.wait_event(ev_xdone[b])
         if timed_events is not None:
             timed_events[0].record(stream)
-        if allow is not None and args.filter_exact:
+        if rccl:
+            tickets[b] = group.search_batch_device_async(qptr, B, k, ef, keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
+                                                         stats.data_ptr() + qb * B * 16, sp)
+        elif allow is not None and args.filter_exact:
             searcher.search_filtered_exact_batch_device(qptr, B, k, allow.data_ptr(), 0, keys.data_ptr(), dists.data_ptr(), counts.data_ptr(), sp)
         elif allow is not None:
             searcher.search_filtered_batch_device(qptr, B, k, ef, allow.data_ptr(), 0, keys.data_ptr(), dists.data_ptr(),
@@ -459,9 +497,9 @@ def main():
             searcher.search_batch_device(qptr, B, k, ef, keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
                                          stats.data_ptr() + qb * B * 16, sp)
         if timed_events is not None:
-            timed_events[1].record(stream)
-        if shard:
-            # exchange step (leann-rs_amd/shard.py): all-gather the per-shard lists over RCCL, merge on every rank
+            timed_events[1].record(stream)  # (the traversal is queued on `stream`; exchange + merge are not inside this bracket)
+        if shard and not rccl:
+            # rehearsal without one GPU per rank (LEANN_BENCH_DIST_BACKEND=gloo): torch all-gather + the HIP merge kernel
             ev_search[b].record(stream)
             xstream.wait_event(ev_search[b])
             with torch.cuda.stream(xstream):
@@ -471,6 +509,14 @@ def main():
                 ev_xdone[b].record(xstream)
             return m_keys
         return keys
+
+    def drain():
+        """all outstanding exchanges have landed"""
+        for b in range(2):
+            if tickets[b] is not None:
+                group.wait(tickets[b], sp)
+                tickets[b] = None
+        stream.synchronize(); xstream.synchronize()
 
     # ---- recall@10 against exact brute force on the same vectors ---------------------------------
     nrq = min(args.recall_queries, B)
@@ -493,25 +539,28 @@ def main():
     log(f"exact ground truth for {nrq} queries in {time.time() - t0:.2f}s")
     truth = gt_k.cpu().numpy()
 
-    def measure_recall():
+    def measure_recall(lo_q, hi_q):
         found = search(0)
-        stream.synchronize(); xstream.synchronize()
-        got = found[:nrq].cpu().numpy()
-        return float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(nrq)]))
+        drain()
+        got = found[lo_q:hi_q].cpu().numpy()
+        return float(np.mean([len(set(got[i].tolist()) & set(truth[lo_q + i].tolist())) / k for i in range(hi_q - lo_q)]))
 
-    if ef_auto and not (allow is not None and args.filter_exact):  # "QPS @ recall@10 >= 0.95": the cheapest beam that still meets the recall bar
+    # "QPS @ recall@10 >= 0.95": the cheapest beam that still meets the bar is picked on the FIRST half of the recall queries and the
+    # recall that goes into the record is measured on the OTHER half (disjoint queries: no tuning on the reported set)
+    half = nrq // 2 if ef_auto and nrq >= 200 else 0
+    if ef_auto and not (allow is not None and args.filter_exact):
         for cand in (40, 48, 56, 64, 72, 80, 96, 112, 128):
             ef = cand
-            if measure_recall() >= 0.955:
+            if measure_recall(0, half or nrq) >= 0.955:
                 break
-        log(f"--ef auto picked ef={ef}")
-    recall = measure_recall()
-    log(f"recall@{k} = {recall:.4f} at ef={ef} ({nrq} queries, corpus {corpus_total} x {d})")
+        log(f"--ef auto picked ef={ef} on recall queries [0, {half or nrq})")
+    recall = measure_recall(half, nrq)
+    log(f"recall@{k} = {recall:.4f} at ef={ef} (recall queries [{half}, {nrq}), corpus {corpus_total} x {d})")
 
     # ---- warmup, then exactly K timed steps between barrier + synchronize -------------------------
     for w in range(args.warmup):
         search(w)
-    stream.synchronize(); xstream.synchronize()
+    drain()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if dist is not None:
         dist.barrier()
@@ -519,7 +568,7 @@ def main():
     t0 = time.perf_counter()
     for s_ in range(args.steps):
         search(s_, ev[s_])
-    stream.synchronize(); xstream.synchronize()
+    drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -542,16 +591,27 @@ def main():
     bytes_per_query = (evals * row_bytes + hops0 * gi["M0"] * 4 + hopsU * gi["M"] * 4) / nq_stat
     bytes_per_launch = bytes_per_query * B
     achieved = bytes_per_launch / kern_avg_s / 1e9
-    traffic = None
+    # HBM traffic per launch comes from rocprofv3 --pmc passes (separate runs: counters cannot be read in-process); the committed figure
+    # is only quoted when this run has the same shape as the profiled one, and its provenance goes into the record
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))  # measured with rocprofv3 --pmc on this exact command (profiles/*.md); only valid for the same beam
-            traffic = tj.get("hbm_bytes_per_launch") if tj.get("ef_search") == ef and B == 16384 and k == 10 and allow is None else None
+            tj = json.load(open(tpath))
+            if tj.get("ef_search") == ef and B == 16384 and k == 10 and allow is None and world == 1:
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = (f"profiles/pmc_traffic_{args.workload}.json — rocprofv3 --pmc of this command at ef={ef} in an earlier run "
+                                  "(FETCH_SIZE x 2 + WRITE_SIZE at the L2<->fabric boundary: Infinity-Cache hits included); not measured in this run")
+            else:
+                traffic_source = f"none: profiles/pmc_traffic_{args.workload}.json was taken at ef={tj.get('ef_search')}, batch 16384, k 10 — this run differs"
         except Exception:
             traffic = None
+    else:
+        traffic_source = "none: no PMC profile committed for this workload"
 
-    units = B * args.steps * world  # query x shard searches (== queries when N == 1 or replica mode)
+    # value: queries answered per second over the WHOLE corpus.  shard mode: every query is searched on all N shards and answered
+    # once (B * K / t); replica mode / N = 1: each rank answers its own batches (N * B * K / t)
+    units = B * args.steps * (1 if shard else world)
     value = units / elapsed
     out = {
         "metric": "queries/sec @ recall@10>=0.95",
@@ -582,7 +642,10 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": ("beam_search_filtered_kernel" if allow is not None else
+            "traffic": traffic, "traffic_source": traffic_source,
+            "boundary_note": "achieved = algorithmic bytes / kernel time; the bytes cross the L2<->fabric boundary, part of them served by the "
+                             "256 MB Infinity Cache rather than HBM (upper levels + hot lists; profiles/r02_hbm_mall_split.md)",
+            "kernel": ("beam_search_filtered_kernel" if allow is not None else
                        "beam_search_feat_kernel<1,8,4> (+ score_mfma_kernel query projection)" if rgraph else
                        "beam_search_kernel<3,4,4,false>" if ld == 768 else "beam_search_kernel"),
             "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_query": bytes_per_query,
@@ -602,9 +665,12 @@ def main():
                            "kernel": "score_mfma_kernel<true> (+ compaction, fold, finalize inside the HIP-event bracket)",
                            "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_flops_per_launch": flops, "allowed_rows": n_allowed}
     if shard:
-        out["end_to_end_qps"] = B * args.steps / elapsed
-        out["config"]["value_unit_note"] = ("value counts query x shard searches (each rank searches every query on its "
-                                            f"{rows}-row shard); end_to_end_qps = value / n_gpus over the {corpus_total}-row corpus")
+        out["shard_searches_per_s"] = B * args.steps * world / elapsed
+        out["config"]["value_unit_note"] = (f"value = end-to-end queries/s over the {corpus_total}-row corpus (every query searched on all "
+                                            f"{world} shards, lists all-gathered over {'RCCL inside the library' if rccl else dist.get_backend()}, merged on every rank); "
+                                            "shard_searches_per_s = value x n_gpus")
+    out["config"]["recall_protocol"] = (f"ef picked on recall queries [0, {half}), recall reported on [{half}, {nrq})" if half else
+                                        f"fixed ef; recall on {nrq} queries")
 
     # ---- PCIe-inclusive rate: the same batch through the host-pointer entry point (queries and results in host memory) ----
     if world == 1 and rank == 0 and allow is None and not rgraph:
@@ -617,6 +683,52 @@ def main():
             out["pcie_inclusive_qps"] = 3 * B / (time.perf_counter() - t0)  # leann_backend_search_batch: H2D of 3 KB per query, D2H of the results, one sync
         except Exception as e:  # noqa: BLE001
             log("host-pointer timing failed:", e)
+
+    # ---- single-query latency: the call the reference actually makes — BackendSearcher::search(query, top_k, complexity)
+    # (src/backend/traits.rs:16-21), one query per call from host memory; and the serve pattern: 64 concurrent single-query callers
+    # (src/cli/serve.rs:289-292), plain and with the library's request coalescing ------------------------------------------------
+    lat = None
+    if world == 1 and rank == 0 and allow is None and not args.no_latency:
+        try:
+            import threading
+            nlat = min(2000, n_pool * B)
+            Ql = Q[:nlat, :d].contiguous().cpu().numpy()
+            kb, db, nb = np.zeros(k, np.uint64), np.zeros(k, np.float32), C.c_size_t(0)
+            f32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+            fn, hnd = L.leann_backend_search, searcher._h
+            for i in range(50):  # warm: workspace, 16-wave instantiation
+                fn(hnd, Ql[i].ctypes.data_as(f32p), k, ef, kb.ctypes.data_as(u64p), db.ctypes.data_as(f32p), C.byref(nb))
+            ts = np.empty(nlat)
+            for i in range(nlat):
+                t0 = time.perf_counter()
+                chk(fn(hnd, Ql[i].ctypes.data_as(f32p), k, ef, kb.ctypes.data_as(u64p), db.ctypes.data_as(f32p), C.byref(nb)))
+                ts[i] = time.perf_counter() - t0
+            lat = {"call": "leann_backend_search (host pointers, 1 query, H2D + kernel + D2H + sync)", "n": int(nlat), "ef": ef, "top_k": k,
+                   "p50_ms": float(np.percentile(ts, 50) * 1e3), "p99_ms": float(np.percentile(ts, 99) * 1e3), "mean_ms": float(ts.mean() * 1e3)}
+
+            def callers(nthreads, per):
+                def work(t):
+                    kk, dd, nn = np.zeros(k, np.uint64), np.zeros(k, np.float32), C.c_size_t(0)
+                    for j in range(per):
+                        q = Ql[(t * per + j) % nlat]
+                        fn(hnd, q.ctypes.data_as(f32p), k, ef, kk.ctypes.data_as(u64p), dd.ctypes.data_as(f32p), C.byref(nn))
+                th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+                t0 = time.perf_counter()
+                [t.start() for t in th]
+                [t.join() for t in th]
+                return nthreads * per / (time.perf_counter() - t0)
+            callers(64, 5)
+            lat["callers64_qps_plain"] = callers(64, 40)
+            searcher.set_coalescing(100, 64)
+            callers(64, 5)
+            lat["callers64_qps_coalesced"] = callers(64, 40)
+            lat["coalescing"] = "leann_backend_set_coalescing(wait_us=100, max_batch=64)"
+            searcher.set_coalescing(0, 0)
+            out["single_query"] = lat
+            log(f"single query: p50 {lat['p50_ms']:.3f} ms, p99 {lat['p99_ms']:.3f} ms; 64 callers: {lat['callers64_qps_plain']:.0f} q/s plain, "
+                f"{lat['callers64_qps_coalesced']:.0f} q/s coalesced")
+        except Exception as e:  # noqa: BLE001
+            log("single-query timing failed:", e)
 
     # ---- CPU baseline: the oracle (C restatement) walking the SAME graph on the host cores --------
     if world == 1 and not args.no_cpu_baseline and rank == 0 and allow is None:
@@ -658,6 +770,16 @@ def main():
                           f"one query per thread on {cores} host threads (oracle/oracle.c, AVX2 canonical dot)",
                 "gpu_results_bit_identical_on_sample": same,
             }
+            if lat is not None:  # the CPU port's latency for ONE query on ONE thread, beside the GPU's single-query latency
+                tc = np.empty(min(300, ncpu))
+                for i in range(len(tc)):
+                    t0 = time.perf_counter()
+                    G.search(Qh[i], k, ef, 0)
+                    tc[i] = time.perf_counter() - t0
+                lat["cpu_port_p50_ms"] = float(np.percentile(tc, 50) * 1e3)
+                lat["cpu_port_p99_ms"] = float(np.percentile(tc, 99) * 1e3)
+                lat["note"] = ("GPU single-query latency is one workgroup of 16 waves walking ~%d dependent hops; the CPU port walks the same "
+                               "graph on one core (warm caches: the sample's rows were just touched by the throughput run)" % round((hops0 + hopsU) / nq_stat))
             log(f"cpu baseline: {ncpu / cpu_s:.0f} q/s on {cores} threads; GPU == oracle on sample: {same}")
         except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
             out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}

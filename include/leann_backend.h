@@ -44,8 +44,16 @@ const char *leann_version(void);
 
 /* ---- BackendType::load_searcher(index_path, dimensions)  src/backend/mod.rs:23-45 -------------
  * `index_path_stem` is ".../documents.leann"; the backend derives "<stem minus .leann>.index"
- * (hnsw.rs:19) or ".diskann" (diskann.rs:22) itself.  `device_spec`: NULL / "" / "0" ... = HIP
- * device ordinal. */
+ * (hnsw.rs:19) or ".diskann" (diskann.rs:22) itself.
+ * `device_spec`: NULL / "" / "0" ... = one HIP device ordinal; a list or range ("0,1,2,3", "0-7"; the same ordinal repeated =
+ * several shards on one device) opens the index SHARDED: the rows (from "<stem>.embeddings", else from this library's own index
+ * file) are split into contiguous position ranges, one sub-index with its own graph per entry, and the returned handle fans every
+ * search out to them and merges the per-shard lists by (dist, key) — see "sharded indexes" below.  The Rust side passes
+ * std::env::var("LEANN_DEVICES") here.
+ * Files: this library's own format ("LEANNGX1": graph + vectors, or graph + encoder inputs for a recompute-on index).  A usearch /
+ * diskann-rs file written by stock leann-rs is not readable; when the directory also holds "<stem>.embeddings"
+ * (src/index/embeddings.rs:21-153) the graph is rebuilt from it on the GPU and cached as "<stem>.gpu.index" / ".gpu.diskann".
+ * Every file is validated (header against file length, every neighbour id / list offset against n) before it reaches the device. */
 int leann_backend_open(const char *index_path_stem, int backend, size_t dims,
                        const char *device_spec, leann_backend **out);
 
@@ -250,6 +258,40 @@ int leann_merge_topk_device(const uint64_t *d_keys, const float *d_dists, const 
                             size_t n_shards, size_t nq, size_t k_in, size_t k_out, int descending,
                             uint64_t *d_out_keys, float *d_out_dists, uint32_t *d_out_counts,
                             void *stream);
+
+/* ---- sharded indexes (the reference has no counterpart: IndexSearcher owns one Box<dyn BackendSearcher>,
+ * src/index/searcher.rs:68) --------------------------------------------------------------------------------------------------
+ * One process, G devices: the composite handle leann_backend_open returns for a device list, or built here from rows / handles.
+ * Every leann_backend_search* entry point works on it (the in-traversal allow-bitmap too; exact / registered filters, graph
+ * export and save do not).  Queries and results of the *_device calls live on the first device of the list.
+ * One process per GPU: leann_sharded_attach joins this rank's shard to an RCCL communicator (librccl.so is resolved at run time);
+ * a search is the local traversal + ONE ncclAllGather of the packed per-shard block {u64 keys | f32 dists | u32 counts} + the merge
+ * kernel on every rank.  All ranks must issue the same calls with the same nq / top_k.
+ * In both modes exchange + merge run on the handle's own stream, so the *_async form lets batch i + 1's traversal overlap batch
+ * i's exchange (two result slots rotate: wait for ticket t before issuing t + 2). */
+typedef struct leann_sharded leann_sharded;
+int leann_sharded_open(const char *index_path_stem, int backend, size_t dims, const char *device_spec, leann_sharded **out);
+/* d_vectors[g]: rows of shard g on devices[g] ([rows[g] x ld] f32, borrowed); keys are rebased by the prefix sums of rows[] */
+int leann_sharded_build_device(int backend, const float *const *d_vectors, const size_t *rows, size_t n_shards, size_t dims,
+                               size_t ld, size_t graph_degree, size_t complexity, const int *devices, leann_sharded **out);
+/* existing handles (each built with its key_offset); take_ownership: leann_sharded_close closes them */
+int leann_sharded_from_handles(leann_backend *const *shards, size_t n_shards, int take_ownership, leann_sharded **out);
+/* wrap a one-process group as an ordinary leann_backend handle (closing that handle closes the group) */
+int leann_sharded_as_backend(leann_sharded *s, leann_backend **out);
+/* RCCL: rank 0 makes the id (128 bytes), the host distributes it by its own means, every rank attaches its shard (collective) */
+int leann_rccl_get_unique_id(void *id128);
+int leann_sharded_attach(leann_backend *local_shard, const void *unique_id128, int world, int rank, size_t total_rows,
+                         leann_sharded **out);
+/* d_stats: optional per-query counters, [n_shards x nq x 4] (one process) / [nq x 4] (RCCL: the local shard's) */
+int leann_sharded_search_batch_device(const leann_sharded *s, const float *d_queries, size_t nq, size_t top_k, size_t complexity,
+                                      uint64_t *d_keys, float *d_dists, uint32_t *d_counts, uint32_t *d_stats, void *stream);
+int leann_sharded_search_batch_device_async(const leann_sharded *s, const float *d_queries, size_t nq, size_t top_k,
+                                            size_t complexity, uint64_t *d_keys, float *d_dists, uint32_t *d_counts,
+                                            uint32_t *d_stats, void *stream, uint64_t *ticket);
+int leann_sharded_wait(const leann_sharded *s, uint64_t ticket, void *stream); /* `stream` waits for that exchange + merge */
+size_t leann_sharded_len(const leann_sharded *s);    /* rows over all shards */
+size_t leann_sharded_shards(const leann_sharded *s);
+void leann_sharded_close(leann_sharded *s);
 
 /* raw device memory helpers so that non-torch hosts (the C++ CLI, ctypes tests) need no HIP binding */
 int leann_device_count(int *n);

@@ -5,7 +5,7 @@ reference's index layer + `leann search` CLI), and this thin ctypes mirror used 
 """
 from ._native import LeannError, lib, device_count, LIB_PATH  # noqa: F401
 from .backend import (BackendBuilder, BackendSearcher, BackendType, DiskAnnSearcher,  # noqa: F401
-                      HnswSearcher)
+                      HnswSearcher, ShardedIndex)
 from .device import DeviceArray, sync  # noqa: F401
 
 

@@ -87,6 +87,19 @@ SIGNATURES = {
     "leann_synth_weights_device": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]),
     "leann_merge_topk_device": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                          C.c_int, vp, vp, vp, vp]),
+    "leann_sharded_open": (C.c_int, [C.c_char_p, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(vp)]),
+    "leann_sharded_build_device": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                            C.c_size_t, C.POINTER(C.c_int), C.POINTER(vp)]),
+    "leann_sharded_from_handles": (C.c_int, [C.POINTER(vp), C.c_size_t, C.c_int, C.POINTER(vp)]),
+    "leann_sharded_as_backend": (C.c_int, [vp, C.POINTER(vp)]),
+    "leann_rccl_get_unique_id": (C.c_int, [vp]),
+    "leann_sharded_attach": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_size_t, C.POINTER(vp)]),
+    "leann_sharded_search_batch_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp]),
+    "leann_sharded_search_batch_device_async": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp, u64p]),
+    "leann_sharded_wait": (C.c_int, [vp, C.c_uint64, vp]),
+    "leann_sharded_len": (C.c_size_t, [vp]),
+    "leann_sharded_shards": (C.c_size_t, [vp]),
+    "leann_sharded_close": (None, [vp]),
     "leann_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "leann_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
     "leann_device_free": (C.c_int, [vp]),

@@ -43,7 +43,8 @@ class BackendSearcher:
     # -- constructors -------------------------------------------------------------------------
     @classmethod
     def load(cls, backend_type, index_path, dimensions, device=0):
-        """HnswSearcher::load (hnsw.rs:18-75) / DiskAnnSearcher::load (diskann.rs:21-43)."""
+        """HnswSearcher::load (hnsw.rs:18-75) / DiskAnnSearcher::load (diskann.rs:21-43).  `device`: an ordinal, or a list / range
+        ("0,1,2,3", "0-7") for a sharded index behind the same handle."""
         h = C.c_void_p()
         N.check(N.lib().leann_backend_open(os.fsencode(str(index_path)), int(backend_type), dimensions,
                                            str(device).encode(), C.byref(h)))
@@ -303,6 +304,96 @@ class Filter:
     def close(self):
         if self._h:
             N.lib().leann_backend_filter_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedIndex:
+    """leann_sharded (include/leann_backend.h "sharded indexes", csrc/shard.hip): the corpus partitioned into contiguous position
+    ranges, one sub-index per shard; a search = per-shard traversal + gather of the per-shard lists + merge kernel.  One process
+    over several devices (open / build_device / from_searchers) or one process per GPU over RCCL (attach)."""
+
+    def __init__(self, handle, keep=()):
+        self._h = handle
+        self._keep = keep  # objects whose device memory the shards borrow
+
+    @classmethod
+    def open(cls, backend_type, index_path, dimensions, device_spec):
+        h = C.c_void_p()
+        N.check(N.lib().leann_sharded_open(os.fsencode(str(index_path)), int(backend_type), dimensions, str(device_spec).encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build_device(cls, backend_type, d_ptrs, rows, dims, ld, graph_degree, complexity, devices, keep=()):
+        G = len(d_ptrs)
+        ptrs = (C.c_void_p * G)(*[C.c_void_p(p) for p in d_ptrs])
+        rws = (C.c_size_t * G)(*rows)
+        devs = (C.c_int * G)(*devices)
+        h = C.c_void_p()
+        N.check(N.lib().leann_sharded_build_device(int(backend_type), ptrs, rws, G, dims, ld, graph_degree, complexity, devs, C.byref(h)))
+        return cls(h, keep)
+
+    @classmethod
+    def from_searchers(cls, searchers, take_ownership=False):
+        G = len(searchers)
+        hs = (C.c_void_p * G)(*[s._h for s in searchers])
+        h = C.c_void_p()
+        N.check(N.lib().leann_sharded_from_handles(hs, G, 1 if take_ownership else 0, C.byref(h)))
+        if take_ownership:
+            for s in searchers:
+                s._h = None
+        return cls(h, tuple(searchers))
+
+    @staticmethod
+    def rccl_unique_id():
+        """128 opaque bytes made by rank 0; the host distributes them to the other ranks by its own means"""
+        buf = C.create_string_buffer(128)
+        N.check(N.lib().leann_rccl_get_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def attach(cls, searcher, unique_id, world, rank, total_rows=0):
+        """join this rank's shard to the RCCL group (collective: every rank calls it)"""
+        h = C.c_void_p()
+        N.check(N.lib().leann_sharded_attach(searcher._h, C.c_char_p(bytes(unique_id)), world, rank, total_rows, C.byref(h)))
+        return cls(h, (searcher,))
+
+    def search_batch_device(self, d_queries, nq, top_k, complexity, d_keys, d_dists, d_counts, d_stats=None, stream=None):
+        N.check(N.lib().leann_sharded_search_batch_device(self._h, d_queries, nq, top_k, complexity, d_keys, d_dists, d_counts, d_stats, stream))
+
+    def search_batch_device_async(self, d_queries, nq, top_k, complexity, d_keys, d_dists, d_counts, d_stats=None, stream=None):
+        """traversal queued behind `stream`, exchange + merge on the handle's own stream; returns a ticket for wait()"""
+        t = C.c_uint64(0)
+        N.check(N.lib().leann_sharded_search_batch_device_async(self._h, d_queries, nq, top_k, complexity, d_keys, d_dists, d_counts, d_stats,
+                                                                stream, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket, stream=None):
+        N.check(N.lib().leann_sharded_wait(self._h, ticket, stream))
+
+    def as_backend(self, backend_type=BackendType.Hnsw):
+        """the same group as an ordinary BackendSearcher handle (closing it closes the group)"""
+        h = C.c_void_p()
+        N.check(N.lib().leann_sharded_as_backend(self._h, C.byref(h)))
+        keep, self._h = self._keep, None
+        s = BackendSearcher(h, backend_type)
+        s._keep = keep
+        return s
+
+    def len(self):
+        return int(N.lib().leann_sharded_len(self._h))
+
+    def n_shards(self):
+        return int(N.lib().leann_sharded_shards(self._h))
+
+    def close(self):
+        if self._h:
+            N.lib().leann_sharded_close(self._h)
             self._h = None
 
     def __del__(self):

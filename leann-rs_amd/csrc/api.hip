@@ -170,12 +170,20 @@ extern "C" void leann_backend_close(leann_backend *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (auto *w : h->free_ws) ws_free(w);
-    leann_internal_free_graph(h);
+    if (h->sharded) leann_sharded_close(h->sharded); // composite handle: the sub-indexes own the device memory
+    else leann_internal_free_graph(h);
     delete h;
 }
 extern "C" size_t leann_backend_len(const leann_backend *h) { return h ? (size_t)h->g.n : 0; }
 extern "C" size_t leann_backend_dims(const leann_backend *h) { return h ? (size_t)h->g.d : 0; }
-extern "C" const float *leann_backend_device_rows(const leann_backend *h) { return h ? h->g.X : nullptr; }
+extern "C" const float *leann_backend_device_rows(const leann_backend *h) { return h && !h->sharded ? h->g.X : nullptr; }
+#define NOT_ON_SHARDED(h, what)                                                                                                    \
+    do {                                                                                                                           \
+        if ((h) && (h)->sharded) {                                                                                                 \
+            leann_set_error("%s is not available on a sharded handle (use the shard handles, or a single-device index)", what);  \
+            return LEANN_ERR_UNSUPPORTED;                                                                                          \
+        }                                                                                                                          \
+    } while (0)
 
 extern "C" int leann_backend_stats(const leann_backend *hc, leann_search_stats *out, int reset) {
     leann_backend *h = const_cast<leann_backend *>(hc);
@@ -346,6 +354,9 @@ extern "C" int leann_backend_search_filtered_batch_device(const leann_backend *h
         HIP_CHECK_RET(hipMemsetAsync(d_counts, 0, nq * 4, st));
         return LEANN_OK;
     }
+    if (h->sharded) // composite handle: fan out, gather, merge (shard.hip); d_stats is [shards x nq x 4] there
+        return leann_internal_sharded_search(h->sharded, d_queries, nq, top_k, complexity, d_allow, allow_stride, d_keys, d_dists, d_counts,
+                                             d_stats, st, nullptr);
     SearchArgs a{};
     a.queries = d_queries;
     a.ldq = h->g.d;
@@ -401,6 +412,7 @@ extern "C" int leann_backend_filter_create(const leann_backend *hc, const uint8_
         return LEANN_ERR_INVALID;
     }
     *out = nullptr;
+    NOT_ON_SHARDED(hc, "a registered filter");
     if (hc->g.n >= (1ull << 32)) {
         leann_set_error("leann_backend_filter_create: the index has 2^32 rows or more");
         return LEANN_ERR_INVALID;
@@ -470,6 +482,7 @@ extern "C" int leann_backend_search_filtered_exact_batch_device(const leann_back
         leann_set_error("leann_backend_search_filtered_exact_batch_device: null/zero argument");
         return LEANN_ERR_INVALID;
     }
+    NOT_ON_SHARDED(h, "exact filtered search");
     if (h->g.feat_h) {
         leann_set_error("exact filtered search needs stored vectors; this index recomputes them from features (use leann_recompute_search_batch_device with an allow mask)");
         return LEANN_ERR_UNSUPPORTED;
@@ -527,6 +540,11 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
         }
     }
     const size_t d = h->g.d, qf = nq * d, no = nq * top_k;
+    const size_t ns = h->sharded ? leann_internal_sharded_count(h->sharded) : 1; // composite handle: per-shard counters
+    if (h->sharded && (exact || flt)) {
+        leann_set_error("exact / registered-filter search is not available on a sharded handle (the in-traversal filter is)");
+        return fail(LEANN_ERR_UNSUPPORTED);
+    }
     auto grow = [&](void **p, size_t &cap, size_t need, size_t elt) -> int {
         if (need <= cap) return 0;
         (void)hipFree(*p);
@@ -537,7 +555,7 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
     };
     if (grow((void **)&w->d_q, w->cap_q, qf, 4) || grow((void **)&w->d_keys, w->cap_keys, no, 8) ||
         grow((void **)&w->d_dists, w->cap_dists, no, 4) || grow((void **)&w->d_counts, w->cap_counts, nq, 4) ||
-        grow((void **)&w->d_stats, w->cap_stats, nq * 4, 4))
+        grow((void **)&w->d_stats, w->cap_stats, ns * nq * 4, 4))
         return fail(LEANN_ERR_DEVICE);
     hipStream_t st = w->stream;
     if (allow) {
@@ -588,15 +606,18 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
         if (hipMemsetAsync(w->d_stats, 0, nq * 16, st) != hipSuccess) return fail(LEANN_ERR_DEVICE);
         rc = leann_internal_filtered_exact(h->g.X, h->g.n, h->g.d, h->g.ld, w->d_q, nq, top_k, w->d_allow, allow_stride, h->key_offset,
                                            w->d_keys, w->d_dists, w->d_counts, st);
+    } else if (h->sharded) {
+        rc = leann_internal_sharded_search(h->sharded, w->d_q, nq, top_k, complexity, a.allow, a.allow_stride, w->d_keys, w->d_dists, w->d_counts,
+                                           w->d_stats, st, nullptr);
     } else {
         rc = leann_internal_launch_search(h, a, st);
     }
     if (rc) return fail(rc);
-    std::vector<uint32_t> hstats(nq * 4);
+    std::vector<uint32_t> hstats(ns * nq * 4);
     if (hipMemcpyAsync(keys, w->d_keys, no * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(dists, w->d_dists, no * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(counts, w->d_counts, nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(hstats.data(), w->d_stats, nq * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(hstats.data(), w->d_stats, ns * nq * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
         leann_set_error("search: device error: %s", hipGetErrorString(hipGetLastError()));
         return fail(LEANN_ERR_DEVICE);
@@ -604,14 +625,15 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
     size_t n_lost = 0;
     {
         std::lock_guard<std::mutex> lk(h->mu);
-        for (size_t i = 0; i < nq; i++) {
+        const GraphView &gv = h->sharded ? leann_internal_sharded_shard(h->sharded, 0)->g : h->g; // (shards share one configuration)
+        for (size_t i = 0; i < ns * nq; i++) {
             h->stats.n_dist_evals += hstats[i * 4 + 0];
             h->stats.n_hops_base += hstats[i * 4 + 1];
             h->stats.n_hops_upper += hstats[i * 4 + 2];
             h->stats.n_table_overflow += hstats[i * 4 + 3] ? 1 : 0;
             n_lost += hstats[i * 4 + 3] == 3;
-            h->stats.algorithmic_bytes += (uint64_t)hstats[i * 4 + 0] * (h->g.feat_h ? h->g.row_bytes : d * 4) + (uint64_t)hstats[i * 4 + 1] * h->g.M0 * 4 +
-                                          (uint64_t)hstats[i * 4 + 2] * h->g.M * 4;
+            h->stats.algorithmic_bytes += (uint64_t)hstats[i * 4 + 0] * (gv.feat_h ? gv.row_bytes : d * 4) + (uint64_t)hstats[i * 4 + 1] * gv.M0 * 4 +
+                                          (uint64_t)hstats[i * 4 + 2] * gv.M * 4;
         }
         h->stats.n_queries += nq;
         h->free_ws.push_back(w);
@@ -890,6 +912,7 @@ extern "C" int leann_backend_graph_info(const leann_backend *h, uint64_t *info) 
 extern "C" int leann_backend_graph_export(const leann_backend *h, uint8_t *levels, uint32_t *upper_off, uint32_t *adj0,
                                           uint32_t *adjU, float *vectors) {
     if (!h) { leann_set_error("leann_backend_graph_export: null handle"); return LEANN_ERR_INVALID; }
+    NOT_ON_SHARDED(h, "graph export");
     HIP_CHECK_RET(hipSetDevice(h->device));
     HIP_CHECK_RET(hipDeviceSynchronize());
     const size_t n = h->g.n;

@@ -479,7 +479,12 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
     size_t s = s0;
     const size_t bu_cap = (b.bmax / 16 + 64) * 16;
     while (s < n) {
-        size_t B = std::min<size_t>(std::min<size_t>(b.bmax, std::max<size_t>(1, s)), n - s);
+        // A batch's points do not see each other, so a batch must stay a small fraction of the graph it is inserted into: at most
+        // 1/8 (LEANN_BUILD_BATCH_FRACTION) of the points already linked.  With batches as large as the graph itself — the first
+        // rule here — two thirds of a 50k-row index went in without seeing their batch mates and recall@10 at ef = 32 fell 1.6
+        // points below the sequential builder's (tests/test_gpu_builder_quality.py); from ~130k rows on the cap is bmax anyway.
+        static const size_t frac = [] { const char *e = getenv("LEANN_BUILD_BATCH_FRACTION"); int v = e ? atoi(e) : 8; return (size_t)(v >= 1 ? v : 8); }();
+        size_t B = std::min<size_t>(std::min<size_t>(b.bmax, std::max<size_t>(1, s / frac)), n - s);
         const uint32_t Lmax = h->g.max_level;
         // ---- phase 1: searches (graph does not contain any point of the batch yet) ----------------
         struct LevelJob { uint32_t level, nq; size_t off; };
@@ -777,9 +782,8 @@ extern "C" int leann_backend_add(int backend, const float *vectors, size_t n, si
     }
     // Append: the new rows continue the batched insertion from the existing graph (hnsw.rs:142-191 adds to the loaded index).
     // Levels are a hash of the position, so the first n_old nodes keep their upper-list offsets; the stored link distances
-    // the builder prunes with are recomputed (link_dist_kernel).  Equal to a one-shot build of the concatenation whenever
-    // the batch boundaries coincide (n_old a power of two <= 16 384 or a multiple of 16 384); otherwise the same algorithm
-    // on a different batch schedule.
+    // the builder prunes with are recomputed (link_dist_kernel).  The same algorithm as a one-shot build of the concatenation on a
+    // different batch schedule (the appended rows are permuted among themselves only).
     const size_t ld = old->g.ld, nt = n_old + n;
     float *dX = nullptr;
     if (hipMalloc((void **)&dX, std::max<size_t>(nt * ld, 4) * 4) != hipSuccess ||

@@ -114,6 +114,7 @@ int leann_internal_save_to(const leann_backend *h, const std::string &path) {
 
 extern "C" int leann_backend_save(const leann_backend *h, const char *index_path_stem) {
     if (!h || !index_path_stem) { leann_set_error("leann_backend_save: null argument"); return LEANN_ERR_INVALID; }
+    if (h->sharded) { leann_set_error("leann_backend_save is not available on a sharded handle (each shard caches its own graph)"); return LEANN_ERR_UNSUPPORTED; }
     try {
         HIP_CHECK_RET(hipSetDevice(h->device));
         return leann_internal_save_to(h, leann_internal_index_file(index_path_stem, h->kind));
@@ -130,7 +131,7 @@ int leann_internal_parse_device(const char *spec, int *device) {
     long v = strtol(spec, &end, 10);
     if (end == spec || *end != 0 || v < 0 || v > 1023) {
         leann_set_error("device_spec \"%s\": expected a HIP device ordinal (\"0\"), a list / range of ordinals for a sharded index "
-                        "(\"0,1,2,3\", \"0-7\"; leann_sharded_open) or \"\"", spec);
+                        "(\"0,1,2,3\", \"0-7\") or \"\"", spec);
         return LEANN_ERR_INVALID;
     }
     *device = (int)v;
@@ -254,6 +255,11 @@ static int rebuild_from_embeddings(const std::string &emb_path, const std::strin
     return LEANN_OK;
 }
 
+int leann_internal_load_own_file(const std::string &path, int backend, size_t dims, int device, leann_backend **out, std::string *why) {
+    int rc = load_own_file(path, backend, dims, device, out, why);
+    return rc == LOAD_FOREIGN ? (int)LEANN_ERR_FORMAT : rc;
+}
+
 static int open_impl(const char *index_path_stem, int backend, size_t dims, int device, leann_backend **out) {
     const std::string path = leann_internal_index_file(index_path_stem, backend);
     FILE *f = fopen(path.c_str(), "rb");
@@ -312,6 +318,8 @@ extern "C" int leann_backend_open(const char *index_path_stem, int backend, size
         leann_set_error("Unknown backend: %d", backend); // searcher.rs:98
         return LEANN_ERR_INVALID;
     }
+    if (leann_internal_spec_is_sharded(device_spec)) // "0-7", "0,1,2,3": one handle over per-device shards (shard.hip)
+        return leann_internal_open_sharded_backend(index_path_stem, backend, dims, device_spec, out);
     int device = 0;
     if (int rc = leann_internal_parse_device(device_spec, &device)) return rc;
     try { // (device availability is checked where the index goes to the device: file errors are reported without a GPU too)

@@ -19,7 +19,9 @@ struct Workspace { // staging of the host-pointer API; one per concurrent caller
 };
 
 struct Coalescer;
+struct leann_sharded;
 struct leann_backend {
+    leann_sharded *sharded = nullptr; // composite handle (shard.hip): searches fan out to the sub-indexes; g holds only n and d
     int kind = LEANN_BACKEND_HNSW, device = 0;
     GraphView g{};
     uint64_t key_offset = 0;
@@ -53,6 +55,15 @@ int leann_internal_from_host(int backend, size_t n, size_t dims, uint32_t M, uin
                              const float *Wf32, int device, uint64_t key_offset, leann_backend **out);
 int leann_internal_save_to(const leann_backend *h, const std::string &path);
 int leann_internal_parse_device(const char *spec, int *device);
+// sharded handles (shard.hip)
+bool leann_internal_spec_is_sharded(const char *spec);
+int leann_internal_open_sharded_backend(const char *stem, int backend, size_t dims, const char *spec, leann_backend **out);
+size_t leann_internal_sharded_count(const leann_sharded *s);
+leann_backend *leann_internal_sharded_shard(const leann_sharded *s, size_t g);
+int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size_t nq, size_t top_k, size_t complexity, const uint8_t *d_allow,
+                                  size_t allow_stride, uint64_t *d_keys, float *d_dists, uint32_t *d_counts, uint32_t *d_stats, hipStream_t st,
+                                  uint64_t *ticket);
+extern "C" void leann_sharded_close(leann_sharded *s);
 
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st);
 

@@ -741,11 +741,14 @@ int leann_internal_filtered_exact(const float *d_rows, size_t n, size_t dims, si
 // Cross-shard merge.  One wave per query; n_shards*k_in <= 4096 entries.
 // Order: ascending (orderable(dist), key)  [descending != 0: descending score, ascending key].
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) merge_topk_kernel(const uint64_t *__restrict__ keys, const float *__restrict__ dists,
-                                                        const uint32_t *__restrict__ counts, uint32_t n_shards,
+__global__ void __launch_bounds__(64) merge_topk_kernel(const unsigned char *__restrict__ keys, const unsigned char *__restrict__ dists,
+                                                        const unsigned char *__restrict__ counts, size_t kstride, size_t dstride,
+                                                        size_t cstride, uint32_t n_shards,
                                                         uint32_t nq, uint32_t k_in, uint32_t k_out, int descending,
                                                         uint64_t *__restrict__ out_keys, float *__restrict__ out_dists,
                                                         uint32_t *__restrict__ out_counts) {
+    // shard s's arrays start s * {k,d,c}stride BYTES after the base pointers: three contiguous [n_shards x nq x k_in] arrays, or one
+    // packed {keys | dists | counts} block per shard as the all-gather delivers them (shard.hip).
     // rank-by-counting: total order has no duplicates across shards (keys are global positions)
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     uint32_t *sd = reinterpret_cast<uint32_t *>(sm);               // [n_shards*k_in] orderable dist
@@ -753,15 +756,15 @@ __global__ void __launch_bounds__(64) merge_topk_kernel(const uint64_t *__restri
     const uint32_t q = blockIdx.x, total = n_shards * k_in;
     for (uint32_t i = threadIdx.x; i < total; i += 64) {
         uint32_t s = i / k_in, j = i % k_in;
-        size_t src = ((size_t)s * nq + q) * k_in + j;
-        bool valid = j < counts[(size_t)s * nq + q];
-        uint32_t od = f32_orderable(dists[src]);
+        const size_t src = (size_t)q * k_in + j;
+        bool valid = j < reinterpret_cast<const uint32_t *>(counts + s * cstride)[q];
+        uint32_t od = f32_orderable(reinterpret_cast<const float *>(dists + s * dstride)[src]);
         sd[i] = valid ? (descending ? ~od : od) : 0xFFFFFFFFu;
-        sk[i] = valid ? keys[src] : ~0ull;
+        sk[i] = valid ? reinterpret_cast<const uint64_t *>(keys + s * kstride)[src] : ~0ull;
     }
     __syncthreads();
     uint32_t nvalid = 0;
-    for (uint32_t s = 0; s < n_shards; s++) nvalid += min(counts[(size_t)s * nq + q], k_in);
+    for (uint32_t s = 0; s < n_shards; s++) nvalid += min(reinterpret_cast<const uint32_t *>(counts + s * cstride)[q], k_in);
     for (uint32_t i = threadIdx.x; i < total; i += 64) {
         uint32_t di = sd[i];
         uint64_t ki = sk[i];
@@ -788,10 +791,10 @@ __global__ void __launch_bounds__(64) merge_topk_kernel(const uint64_t *__restri
     if (threadIdx.x == 0) out_counts[q] = nout;
 }
 
-extern "C" int leann_merge_topk_device(const uint64_t *d_keys, const float *d_dists, const uint32_t *d_counts,
-                                       size_t n_shards, size_t nq, size_t k_in, size_t k_out, int descending,
-                                       uint64_t *d_out_keys, float *d_out_dists, uint32_t *d_out_counts, void *stream) {
-    if (!d_keys || !d_dists || !d_counts || !d_out_keys || !d_out_dists || !d_out_counts || n_shards == 0 ||
+int leann_internal_merge_strided(const void *keys, const void *dists, const void *counts, size_t kstride, size_t dstride, size_t cstride,
+                                 size_t n_shards, size_t nq, size_t k_in, size_t k_out, int descending, uint64_t *d_out_keys,
+                                 float *d_out_dists, uint32_t *d_out_counts, hipStream_t st) {
+    if (!keys || !dists || !counts || !d_out_keys || !d_out_dists || !d_out_counts || n_shards == 0 ||
         k_in == 0 || k_out == 0 || n_shards * k_in > 4096) {
         leann_set_error("leann_merge_topk_device: invalid arguments (shards=%zu k_in=%zu k_out=%zu)", n_shards, k_in, k_out);
         return LEANN_ERR_INVALID;
@@ -799,9 +802,16 @@ extern "C" int leann_merge_topk_device(const uint64_t *d_keys, const float *d_di
     if (nq == 0) return LEANN_OK;
     size_t total = n_shards * k_in;
     size_t lds = ((total * 4 + 7) & ~(size_t)7) + total * 8;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), lds, (hipStream_t)stream, d_keys, d_dists,
-                       d_counts, (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k_in, (uint32_t)k_out, descending,
-                       d_out_keys, d_out_dists, d_out_counts);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), lds, st, (const unsigned char *)keys, (const unsigned char *)dists,
+                       (const unsigned char *)counts, kstride, dstride, cstride, (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k_in,
+                       (uint32_t)k_out, descending, d_out_keys, d_out_dists, d_out_counts);
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
+}
+
+extern "C" int leann_merge_topk_device(const uint64_t *d_keys, const float *d_dists, const uint32_t *d_counts,
+                                       size_t n_shards, size_t nq, size_t k_in, size_t k_out, int descending,
+                                       uint64_t *d_out_keys, float *d_out_dists, uint32_t *d_out_counts, void *stream) {
+    return leann_internal_merge_strided(d_keys, d_dists, d_counts, nq * k_in * 8, nq * k_in * 4, nq * 4, n_shards, nq, k_in, k_out, descending,
+                                        d_out_keys, d_out_dists, d_out_counts, (hipStream_t)stream);
 }

@@ -171,10 +171,54 @@ def test_recompute_on_graph_search(la, po, gpu):
     assert (k2 == gk).mean() >= 0.99  # identical except across float near-ties
     # (c) recall against exact search over the true embeddings
     assert recall_at_k(gk, po.exact_topk(E, Q, k)) >= 0.93
-    with pytest.raises(la.LeannError, match="no vectors"):
-        s.save("/tmp/x.leann")
     s2.close()
     s.close()
+    Lc.leann_recompute_close(r)
+
+
+def test_recompute_on_graph_index_round_trips_through_its_file(la, po, gpu, tmp_path):
+    """The LEANN state proper — graph kept, vectors dropped (src/index/meta.rs:38-42 is_pruned, src/cli/prune.rs:17-79) — saved and
+    reopened: format v2 holds the graph, the bf16 feature rows and the encoder weights; the reopened handle answers bit for bit like
+    the in-memory one and holds the same bytes."""
+    n, h, d, nq, k = 12000, 256, 384, 64, 10
+    Lc, chk = la.lib(), la._native.check
+    F = po.synth_features(SEED, h, 64, 1.0, 0, 0, n)
+    W = po.synth_weights(SEED, h, d)
+    Q = po.recompute_encode(po.synth_features(SEED, h, 64, 1.0, 1, 0, nq), W)
+    dF, dW = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W)
+    r = C.c_void_p()
+    chk(Lc.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))
+    for backend, deg in ((0, 16), (1, 32)):
+        hb = C.c_void_p()
+        chk(Lc.leann_recompute_build_index(r, backend, deg, 64, C.byref(hb)))
+        s = la.BackendSearcher(hb, backend)
+        stem = str(tmp_path / f"b{backend}" / "documents.leann")
+        (tmp_path / f"b{backend}").mkdir()
+        s.save(stem)
+        fname = tmp_path / f"b{backend}" / ("documents.diskann" if backend else "documents.index")
+        rows_b = n * 520
+        g = s.graph_export()
+        assert fname.stat().st_size == 128 + n + 4 * n + 4 * n * g["M0"] + 4 * g["n_upper_lists"] * g["M"] + rows_b + 4 * h * d
+        s2 = la.BackendSearcher.load(backend, stem, d)
+        g2 = s2.graph_export()
+        for key in ("n", "dims", "M", "M0", "max_level", "entry", "n_upper_lists"):
+            assert g[key] == g2[key], key
+        for key in ("levels", "upper_off", "adj0", "adjU"):
+            assert (g[key] == g2[key]).all(), key
+        rows1, rows2 = np.zeros((n, 520), np.uint8), np.zeros((n, 520), np.uint8)
+        chk(Lc.leann_backend_feature_rows_export(s._h, None, None, rows1.ctypes.data))
+        chk(Lc.leann_backend_feature_rows_export(s2._h, None, None, rows2.ctypes.data))
+        assert (rows1 == rows2).all()
+        for ef in (10, 64, 200):
+            k1, d1, c1 = s.search_batch(Q, k, ef)
+            k2, d2, c2 = s2.search_batch(Q, k, ef)
+            assert (k1 == k2).all() and (d1.view(np.uint32) == d2.view(np.uint32)).all() and (c1 == c2).all()
+        with pytest.raises(la.LeannError, match="holds no vectors"):
+            s2.graph_export(with_vectors=True)
+        with pytest.raises(la.LeannError):  # wrong backend kind for this file
+            la.BackendSearcher.load(1 - backend, str(tmp_path / f"b{backend}" / "documents.leann"), d)
+        s2.close()
+        s.close()
     Lc.leann_recompute_close(r)
 
 

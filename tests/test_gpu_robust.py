@@ -227,3 +227,80 @@ def test_request_coalescing_for_single_query_callers(la, po, gpu):
     assert (s.search(Q[3], 10, 64)[0] == ref_k[3]).all()
     print(f"single-query callers: plain {len(Q)/t_plain:.0f} q/s, coalesced {len(Q)/t_coal:.0f} q/s, launches {st['launches']}")
     s.close()
+
+
+def test_visited_set_never_runs_out(la, po, gpu, monkeypatch):
+    """a query that outgrew even its pooled HBM table used to come back EMPTY with LEANN_OK.  Now it moves on to a
+    second-level table sized to hold every node of the index; results and counters stay identical to the oracle's.  The debug knobs
+    shrink the pools so that a 60k-row index exercises LDS -> pool 1 -> pool 2; with pool 2 shrunk below the index size the defensive
+    path must report LEANN_ERR_OVERFLOW instead of an empty answer."""
+    n, d, M = 60000, 64, 16
+    X = synth(po, n, d, r=0)  # i.i.d.: searches wander
+    Q = synth(po, 128, d, stream=1, r=0)
+    dX = la.DeviceArray.from_host(X)
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, d, M, 32)
+    g = s.graph_export()
+    G = po.Graph.from_arrays(X, M, 2 * M, g["max_level"], g["entry"], g["levels"], g["upper_off"], g["adj0"], g["adjU"])
+    ok, od, oc, ost = G.search_batch(Q, 10, 400, 0, nthreads=8)
+    assert int(ost[:, 0].min()) > 3500  # every query visits far more than a 2^10-slot (or 2^12-slot) table holds
+    s.close()
+    monkeypatch.setenv("LEANN_DEBUG_HASH_BITS", "8")     # LDS table: 256 slots
+    monkeypatch.setenv("LEANN_DEBUG_GPOOL_BITS", "10")   # pool 1: 1 024 slots -> pool 2 (sized by n)
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, d, M, 32)  # (the pools are sized at first use, per handle)
+    s.stats(reset=True)
+    gk, gd, gc = s.search_batch(Q, 10, 400)
+    st = s.stats()
+    assert (gc == oc).all() and (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    assert st["n_dist_evals"] == int(ost[:, 0].sum()) and st["n_table_overflow"] == len(Q)
+    k1, d1 = s.search(Q[7], 10, 400)  # 16-wave single-query mode through the same escalation
+    assert (k1 == ok[7]).all() and (d1 == od[7]).all()
+    s.close()
+    monkeypatch.setenv("LEANN_DEBUG_GPOOL2_BITS", "12")  # defensive path: even the last level is too small
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, d, M, 32)
+    with pytest.raises(la.LeannError) as e:
+        s.search_batch(Q, 10, 400)
+    assert e.value.code == 7 and "visited-set space" in str(e.value)
+    gk, gd, gc = s.search_batch(Q, 10, 8)  # a narrow beam on the same handle still fits and still matches
+    ok8, od8, oc8, _ = G.search_batch(Q, 10, 8, 0, nthreads=8)
+    assert (gk == ok8).all() and (gd.view(np.uint32) == od8.view(np.uint32)).all()
+    s.close()
+
+
+def test_coalescing_can_be_reconfigured_while_searches_are_in_flight(la, po, gpu):
+    """set_coalescing used to hold the handle's mutex while joining the dispatcher (deadlock with a pending launch) and
+    deleted the object waiters were blocked on.  Now: reconfigure / disable from one thread while 32 threads search."""
+    import time
+    X = synth(po, 20000, 64)
+    dX = la.DeviceArray.from_host(X)
+    s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, 20000, 64, 64, 16, 64)
+    Q = synth(po, 32 * 40, 64, stream=1)
+    ref_k, ref_d, _ = s.search_batch(Q, 10, 48)
+    bad, stop = [], threading.Event()
+
+    def work(t):
+        for j in range(40):
+            i = t * 40 + j
+            k, dd = s.search(Q[i], 10, 48)
+            if not ((k == ref_k[i]).all() and (dd == ref_d[i]).all()):
+                bad.append(i)
+
+    def flip():
+        modes = [(200, 64), (0, 0), (50, 8), (1000, 4096), (0, 0), (300, 16)]
+        j = 0
+        while not stop.is_set():
+            s.set_coalescing(*modes[j % len(modes)])
+            j += 1
+            time.sleep(0.002)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(32)]
+    fl = threading.Thread(target=flip)
+    fl.start()
+    [t.start() for t in th]
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a searcher thread is stuck (deadlock between set_coalescing and a pending launch)"
+    stop.set()
+    fl.join(timeout=30)
+    assert not fl.is_alive() and not bad
+    s.set_coalescing(0, 0)
+    s.close()

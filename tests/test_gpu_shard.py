@@ -38,3 +38,124 @@ def test_simulated_shards_match_oracle(la, po, gpu, G):
         rk, rd = po.merge_topk(np.stack(ok)[:, q], np.stack(od)[:, q], np.stack(oc)[:, q], k)
         assert (mk[q] == rk).all() and (md[q] == rd).all()
     assert recall_at_k(mk, po.exact_topk(X, Q, k)) >= 0.93
+
+
+def _per_shard_reference(la, po, X, Q, k, ef, G, M, lows, allow=None):
+    """the pre-existing path: every shard searched on its own, lists merged by leann_merge_topk_device; plus the oracle doing the same"""
+    n, nq = len(X), len(Q)
+    gk, gd, gc, ok, od, oc, evals = [], [], [], [], [], [], 0
+    for g in range(G):
+        lo, hi = lows[g], lows[g + 1]
+        dX = la.DeviceArray.from_host(X[lo:hi])
+        s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, hi - lo, X.shape[1], X.shape[1], M, 48, key_offset=lo)
+        gr = s.graph_export()
+        Gr = po.Graph.from_arrays(X[lo:hi], M, 2 * M, gr["max_level"], gr["entry"], gr["levels"], gr["upper_off"], gr["adj0"], gr["adjU"])
+        if allow is None:
+            kk, dd, cc = s.search_batch(Q, k, ef)
+            k0, d0, c0, st = Gr.search_batch(Q, k, ef, 0, 4)
+        else:
+            sl = allow[lo // 8:]
+            kk, dd, cc = s.search_filtered_batch(Q, k, ef, sl[: (hi - lo + 7) // 8])
+            k0, d0, c0, st = Gr.search_filtered_batch(Q, k, ef, sl[: (hi - lo + 7) // 8], 0, 4)
+        k0 = np.where(d0 == np.inf, np.iinfo(np.uint64).max, k0 + np.uint64(lo))
+        assert (kk == k0).all() and (dd == d0).all()
+        evals += int(st[:, 0].sum())
+        gk.append(kk); gd.append(dd); gc.append(cc)
+        s.close()
+    gk, gd, gc = np.stack(gk), np.stack(gd), np.stack(gc)
+    dk, dd_, dc = la.DeviceArray.from_host(gk), la.DeviceArray.from_host(gd), la.DeviceArray.from_host(gc)
+    mk, md, mc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    la._native.check(la.lib().leann_merge_topk_device(dk.ptr, dd_.ptr, dc.ptr, G, nq, k, k, 0, mk.ptr, md.ptr, mc.ptr, None))
+    la.sync()
+    return mk.to_host(), md.to_host(), mc.to_host(), evals
+
+
+@pytest.mark.parametrize("G", [1, 2, 4, 8])
+def test_sharded_handle_behind_the_c_abi(la, po, gpu, G):
+    """partition + fan-out + gather + merge INSIDE the library.  G simulated shards on one device through ONE
+    leann_backend handle (leann_sharded_build_device -> leann_sharded_as_backend): byte-identical to the per-shard searches merged
+    by leann_merge_topk_device, for the host-pointer batch call, the single-query trait call, the device call, the pipelined
+    (ticket) form, and the in-traversal allow-bitmap; counters aggregate over the shards."""
+    n, d, nq, k, ef, M = 8192 + 640, 128, 40, 10, 48, 12
+    X = synth(po, n, d)
+    Q = synth(po, nq, d, stream=1)
+    lows = [0] + [((n * g) // G) & ~63 for g in range(1, G)] + [n]  # interior boundaries at multiples of 64 (bitmaps slice at bytes)
+    mk, md, mc, evals = _per_shard_reference(la, po, X, Q, k, ef, G, M, lows)
+    parts = [la.DeviceArray.from_host(X[lows[g]:lows[g + 1]]) for g in range(G)]
+    sh = la.ShardedIndex.build_device(la.BackendType.Hnsw, [p.ptr for p in parts], [lows[g + 1] - lows[g] for g in range(G)], d, d, M, 48,
+                                      [0] * G, keep=parts)
+    assert sh.len() == n and sh.n_shards() == G
+    # device call + pipelined form on the group itself
+    dQ = la.DeviceArray.from_host(Q)
+    outs = [(la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)) for _ in range(3)]
+    sh.search_batch_device(dQ.ptr, nq, k, ef, outs[0][0].ptr, outs[0][1].ptr, outs[0][2].ptr)
+    t1 = sh.search_batch_device_async(dQ.ptr, nq, k, ef, outs[1][0].ptr, outs[1][1].ptr, outs[1][2].ptr)
+    t2 = sh.search_batch_device_async(dQ.ptr, nq, k, ef, outs[2][0].ptr, outs[2][1].ptr, outs[2][2].ptr)
+    sh.wait(t1)
+    sh.wait(t2)
+    with pytest.raises(la.LeannError, match="not outstanding"):
+        sh.wait(t2 + 5)
+    la.sync()
+    for o in outs:
+        assert (o[0].to_host() == mk).all() and (o[1].to_host() == md).all() and (o[2].to_host() == mc).all()
+    # ... and as ONE ordinary backend handle
+    s = sh.as_backend()
+    assert s.len() == n and s.dims() == d
+    s.stats(reset=True)
+    hk, hd, hc = s.search_batch(Q, k, ef)
+    assert (hk == mk).all() and (hd == md).all() and (hc == mc).all()
+    st = s.stats()
+    assert st["n_queries"] == nq and st["n_dist_evals"] == evals
+    k1, d1 = s.search(Q[3], k, ef)
+    assert (k1 == mk[3]).all() and (d1 == md[3]).all()
+    assert recall_at_k(hk, po.exact_topk(X, Q, k)) >= 0.93
+    # in-traversal filter: one global bitmap, sliced per shard inside the library
+    rng = np.random.default_rng(G)
+    bits = rng.random(n) < 0.3
+    allow = np.packbits(bits, bitorder="little")
+    fk, fd, fc, _ = _per_shard_reference(la, po, X, Q, k, ef, G, M, lows, allow=allow)
+    gk, gd, gc = s.search_filtered_batch(Q, k, ef, allow)
+    assert (gk == fk).all() and (gd == fd).all() and (gc == fc).all()
+    assert all(bits[int(x)] for x in gk[gk != np.iinfo(np.uint64).max])
+    # what a composite handle cannot do says so
+    for fn in (lambda: s.graph_export(), lambda: s.save("/tmp/nope.leann"), lambda: s.register_filter(allow),
+               lambda: s.search_filtered_exact_batch(Q, k, allow)):
+        with pytest.raises(la.LeannError, match="sharded handle"):
+            fn()
+    s.set_coalescing(100, 64)  # the coalescer sits on top of the composite handle like on any other
+    k2, d2 = s.search(Q[5], k, ef)
+    assert (k2 == mk[5]).all()
+    s.set_coalescing(0, 0)
+    s.close()
+
+
+def test_open_with_a_device_list_shards_a_stock_directory(la, po, gpu, tmp_path):
+    """leann_backend_open(stem, ..., "0,0,0"): rows from documents.embeddings split three ways, graphs cached per shard"""
+    import os
+    n, d = 30_000, 64
+    X = synth(po, n, d)
+    X.tofile(tmp_path / "documents.embeddings")
+    (tmp_path / "documents.index").write_bytes(b"usearch" + bytes(300))
+    stem = str(tmp_path / "documents.leann")
+    s = la.BackendSearcher.load(la.BackendType.Hnsw, stem, d, device="0,0,0")
+    assert s.len() == n
+    Q = synth(po, 100, d, stream=1)
+    k1, d1, _ = s.search_batch(Q, 10, 64)
+    assert recall_at_k(k1, po.exact_topk(X, Q, 10)) >= 0.95
+    s.close()
+    caches = sorted(f for f in os.listdir(tmp_path) if "shard" in f)
+    assert caches == ["documents.shard0of3.gpu.index", "documents.shard1of3.gpu.index", "documents.shard2of3.gpu.index"]
+    s = la.BackendSearcher.load(la.BackendType.Hnsw, stem, d, device="0,0,0")  # second open: from the caches
+    k2, d2, _ = s.search_batch(Q, 10, 64)
+    assert (k1 == k2).all() and (d1 == d2).all()
+    s.close()
+    with pytest.raises(la.LeannError, match="device_spec"):
+        la.BackendSearcher.load(la.BackendType.Hnsw, stem, d, device="0,x")
+    # the library's own single-file index is a row source too
+    (tmp_path / "own").mkdir()
+    la.BackendBuilder(la.BackendType.Hnsw).build(X[:5000], [], str(tmp_path / "own" / "documents.leann"), d, 12, 48)
+    s = la.BackendSearcher.load(la.BackendType.Hnsw, str(tmp_path / "own" / "documents.leann"), d, device="0-0,0")
+    assert s.len() == 5000
+    k3, _, _ = s.search_batch(Q, 10, 64)
+    assert recall_at_k(k3, po.exact_topk(X[:5000], Q, 10)) >= 0.95
+    s.close()
