@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 evidence for the headline bench line (run on the GPU box from the repo root): kernel-trace + stats of the default bench
+# command, then SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE, L2 hit/miss) as MI355X_MICROARCH.md §HBM prescribes.
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+out=$R/gpurun_out/r02
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -o r02 -- python3 $R/bench.py --no-cpu-baseline --no-latency > $out/prof_stats.json 2> $out/prof_stats.log
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $c | tr ' ' '_')
+  rocprofv3 --pmc $c --kernel-include-regex "beam_search_kernel" --output-format csv -d $out/prof_$tag -o r02 -- python3 $R/bench.py --no-cpu-baseline --no-latency --steps 4 --warmup 1 > $out/prof_$tag.json 2> $out/prof_$tag.log || echo "pmc pass $c failed"
+done
+rocprofv3 -L 2>/dev/null | grep -i -E "mall|dram|EA0_RDREQ" | head -40 > $out/counters_mem.txt || true
+ls $out

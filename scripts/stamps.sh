@@ -1,12 +1,8 @@
 #!/bin/bash
-# Diagnostic build with in-kernel s_memtime stamps (never shipped: outputs go to gpurun_out/, timings of this
-# build are not quotable — read the SHARES).  Usage: scripts/stamps.sh  (on the GPU box)
+# Diagnostic build with in-kernel s_memtime stamps (-DLEANN_STAMPS); prints where a hop / a unit spends its cycles.
+#   scripts/stamps.sh [rows] [ef] [feat]          traversal kernel (phases B / C / D per hop)
+#   scripts/stamps.sh fstat [args]                fused recompute kernel
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out/stamps
-for f in api build gen scan recompute; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -DLEANN_STAMPS -c leann-rs_amd/csrc/$f.hip -o gpurun_out/stamps/$f.o &
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_out/stamps/libleann_hip_stamps.so gpurun_out/stamps/*.o
-if [ "$1" = "fstat" ]; then shift; LEANN_LIB=$PWD/gpurun_out/stamps/libleann_hip_stamps.so python scripts/stamps_fstat.py "$@"; else LEANN_LIB=$PWD/gpurun_out/stamps/libleann_hip_stamps.so python scripts/stamps.py "$@"; fi
+if [ "$1" = "fstat" ]; then shift; exec scripts/variant.sh "-DLEANN_STAMPS" python scripts/stamps_fstat.py "$@"; fi
+exec scripts/variant.sh "-DLEANN_STAMPS" python scripts/stamps.py "$@"

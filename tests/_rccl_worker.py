@@ -23,8 +23,10 @@ def main(out):
     L, chk = la.lib(), la._native.check
     n, d, nq, k, ef = 6000 * world, 128, 48, 10, 64
     g = torch.Generator(device="cpu").manual_seed(7)
-    X = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).to(dev)  # the whole corpus on every rank (small): ground truth
-    Q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).to(dev)
+    centres = torch.randn(96, d, generator=g)  # clustered rows (i.i.d. 128-d Gaussians are adversarial for any graph index)
+    X = torch.nn.functional.normalize(centres[torch.randint(0, 96, (n,), generator=g)] + 0.35 * torch.randn(n, d, generator=g), dim=1).to(dev)
+    Q = torch.nn.functional.normalize(centres[torch.randint(0, 96, (nq,), generator=g)] + 0.35 * torch.randn(nq, d, generator=g), dim=1).to(dev)
+    # (the whole corpus on every rank — it is small — serves as ground truth)
     lo, hi = shard_range(n, world, rank)
     s = la.BackendSearcher.build_device(la.BackendType.Hnsw, X[lo:hi].contiguous().data_ptr(), hi - lo, d, d, 12, 48, device=local,
                                         key_offset=lo, take_copy=True)
