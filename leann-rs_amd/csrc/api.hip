@@ -299,7 +299,7 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
         a.ldq = h->g.feat_h;
         const int T = (int)((h->g.feat_h + 255) / 256);
         switch (T) {
-            case 1: return launch_search_feat<1, 8>(h->g, a, st);
+            case 1: return launch_search_feat<1, LEANN_FEAT_R1>(h->g, a, st);
             case 2: return launch_search_feat<2, 6>(h->g, a, st);
             case 3: case 4: return launch_search_feat<4, 4>(h->g, a, st);
             default: leann_set_error("recompute-on index: feature width %u > 1024 not supported", h->g.feat_h); return LEANN_ERR_INVALID;

@@ -161,6 +161,13 @@ __device__ __forceinline__ void wave_dist_rows_feat(const float4 (&q)[T], const 
     }
 }
 
+// neighbour list of `node` on level lv: level 0 lists are [n x M0], upper lists [n_upper_lists x M] at upper_off[node] + lv - 1
+__device__ __forceinline__ const uint32_t *adj_list(const uint32_t *__restrict__ base, const uint32_t *__restrict__ upper_off, uint32_t deg,
+                                                    int lv, uint32_t node) {
+    const size_t list = lv == 0 ? (size_t)node : (size_t)upper_off[node] + (uint32_t)(lv - 1);
+    return base + list * deg;
+}
+
 // LDS carve-up (dynamic): [W0 | W1 | s_key | s_new | misc | (filtered: R0 | R1 | s_keyR) | table]
 struct SearchLds {
     uint64_t *s_key;
@@ -216,6 +223,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         for (int t = 0; t < T; t++) q[t] = vec_load4_guard(qv, dq, t, lane);
     }
 
+    const uint32_t *const adj0_p = g.adj0, *const adjU_p = g.adjU, *const upoff_p = g.upper_off;
     uint32_t n_evals = 1, hops0 = 0, hopsU = 0; // meaningful in wave 0 / lane 0 only
     uint32_t n_vis = 0;
     uint64_t best;
@@ -267,6 +275,14 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         n_vis = 1;
         uint32_t sel = 0;
         uint32_t hop = 0;
+        // Adjacency list of the NEXT node to expand, one neighbour id per lane of wave 0 (lists hold at most 64 ids).  The load is
+        // issued as soon as the next candidate is known — right after the new distances exist, BEFORE the merge (phase E below) —
+        // so its HBM round trip runs under the merge and the barrier instead of at the head of the next hop.
+        uint32_t e_pref = LEANN_EMPTY;
+        // (level-dependent pieces of the list address as VALUES: selecting between the two struct members by address makes hipcc keep
+        // the by-value GraphView in scratch memory)
+        const uint32_t *const adj_base = lv == 0 ? adj0_p : adjU_p;
+        if (wave == 0) e_pref = (uint32_t)lane < deg ? adj_list(adj_base, upoff_p, deg, lv, key_id(best))[lane] : LEANN_EMPTY;
         while (sel != LEANN_EMPTY) {
             uint64_t *Wc = W0 + cur * efp, *Wn = W0 + (cur ^ 1) * efp;
 #ifdef LEANN_STAMPS // diagnostic build only (scripts/stamps.sh): where does a hop spend its cycles?
@@ -277,20 +293,16 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 const uint32_t node = key_id(Wc[sel]);
                 if (a.out_expanded && lv == (int)a.target_level && lane == 0 && hop < a.exp_cap)
                     a.out_expanded[(size_t)qi * a.exp_cap + hop] = ((Wc[sel] >> 32) << 32) | node;
-                const uint32_t *adj = lv == 0 ? g.adj0 + (size_t)node * g.M0
-                                              : g.adjU + ((size_t)g.upper_off[node] + (uint32_t)(lv - 1)) * g.M;
                 uint32_t n_new = 0;
                 bool ovf = (n_vis + deg > vis_limit);
                 if (!ovf) {
-                    for (uint32_t base = 0; base < deg; base += 64) {
-                        uint32_t e = (base + lane < deg) ? adj[base + lane] : LEANN_EMPTY;
-                        bool isnew = false;
-                        if (e != LEANN_EMPTY) isnew = hbm ? vis_insert_hbm(gtab, gbits, gen, e) : vis_insert_lds(table, hbits, e);
-                        unsigned long long m = __ballot(isnew);
-                        uint32_t pos = n_new + __popcll(m & ((1ull << lane) - 1ull));
-                        if (isnew) s.s_new[pos] = e;
-                        n_new += __popcll(m);
-                    }
+                    const uint32_t e = e_pref; // this node's list (a hop redone after a table migration reads the same register again)
+                    bool isnew = false;
+                    if (e != LEANN_EMPTY) isnew = hbm ? vis_insert_hbm(gtab, gbits, gen, e) : vis_insert_lds(table, hbits, e);
+                    unsigned long long m = __ballot(isnew);
+                    uint32_t pos = __popcll(m & ((1ull << lane) - 1ull));
+                    if (isnew) s.s_new[pos] = e;
+                    n_new = __popcll(m);
                 }
                 n_vis += n_new;
                 n_evals += n_new;
@@ -299,7 +311,6 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 if (filt_level && lane < 8) s_keyR[n_new + lane] = ~0ull;
                 if (lane == 0) {
                     s.misc[0] = n_new;
-                    s.misc[1 + (hop & 1)] = LEANN_EMPTY; // slot THIS hop's merge mins into (last read two hops ago)
                     if (ovf) s.misc[3] = 1;
                 }
             }
@@ -392,41 +403,72 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
 #ifdef LEANN_STAMPS
             const uint64_t stB2 = __builtin_amdgcn_s_memtime();
 #endif
-            // ---- phase D: merge by rank into the other buffer; pick the next candidate ----------
-            // One work item per old entry (rank = index + #new keys below it) and per new key (rank = #old below it, by
-            // binary search, + #new below it); the scan over the new keys reads 16 B per LDS instruction, 8 keys per
-            // unrolled step, so the loads pipeline instead of paying one LDS latency per key.
+            // ---- phase E (wave 0): the next candidate, known before the merge -------------------------------------
+            // The merged beam's first unexpanded entry is the smaller of (a) the first unexpanded entry of the OLD beam other than
+            // the one just expanded and (b) the smallest new key; its index in the merged beam is the number of keys below it.
+            // Same entry, same index as a scan of the merged list would give — but available one merge earlier, so wave 0 issues
+            // the next hop's adjacency load now and the other waves merge meanwhile.
             uint32_t *next_slot = &s.misc[1 + (hop & 1)];
             const uint32_t n_pad = (n_new + 7) & ~7u;
-            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(s.s_key);
-            for (uint32_t it = tid; it < ((wsize + n_new + 63) & ~63u); it += NW * 64) { // whole waves: wave_min below
-                const bool valid = it < wsize + n_new, isW = it < wsize;
-                uint64_t k = !valid ? ~0ull : (isW ? Wc[it] : s.s_key[it - wsize]);
-                if (isW && it == sel) k |= 1ull;
-                const uint64_t kk = k >> 1;
-                uint32_t cnt = 0;
-#pragma unroll 4
-                for (uint32_t j = 0; j < n_pad; j += 2) {
-                    const ulonglong2 v = kp[j >> 1];
-                    cnt += ((v.x >> 1) < kk) + ((v.y >> 1) < kk);
+            if (wave == 0) {
+                uint32_t u = LEANN_EMPTY;
+                for (uint32_t base = 0; base < wsize && u == LEANN_EMPTY; base += 64) {
+                    const uint32_t i = base + lane;
+                    const unsigned long long m = __ballot(i < wsize && i != sel && !(Wc[i] & 1ull));
+                    if (m) u = base + (uint32_t)__ffsll((long long)m) - 1u;
                 }
-                uint32_t rank = isW ? it + cnt : cnt;
-                if (valid && !isW) {
-                    uint32_t lo = 0, hi = wsize;
-                    while (lo < hi) {
-                        uint32_t mid = (lo + hi) >> 1;
-                        if ((Wc[mid] >> 1) < kk) lo = mid + 1; else hi = mid;
+                const uint64_t c_old = u != LEANN_EMPTY ? Wc[u] : ~0ull;
+                const uint64_t kj = (uint32_t)lane < n_new ? s.s_key[lane] : ~0ull; // n_new <= 64: one key per lane
+                const uint32_t hi = wave_min_u32((uint32_t)(kj >> 32));
+                const uint32_t lo = wave_min_u32((uint32_t)(kj >> 32) == hi ? (uint32_t)kj : 0xFFFFFFFFu);
+                const uint64_t c_new = n_new ? (((uint64_t)hi << 32) | lo) : ~0ull;
+                uint32_t next = LEANN_EMPTY, cnode = 0;
+                if (c_old != ~0ull || c_new != ~0ull) {
+                    uint32_t rank;
+                    if ((c_old >> 1) < (c_new >> 1)) {
+                        rank = u + (uint32_t)__popcll(__ballot((kj >> 1) < (c_old >> 1)));
+                        cnode = key_id(c_old);
+                    } else {
+                        rank = 0;
+                        for (uint32_t base = 0; base < wsize; base += 64) {
+                            const uint32_t i = base + lane;
+                            rank += (uint32_t)__popcll(__ballot(i < wsize && (Wc[i] >> 1) < (c_new >> 1)));
+                        }
+                        cnode = key_id(c_new);
                     }
-                    rank += lo;
+                    if (rank < ef_l) next = rank;
                 }
-                uint32_t cand = LEANN_EMPTY;
-                if (valid && rank < ef_l) {
-                    Wn[rank] = k;
-                    if (!(k & 1ull)) cand = rank;
+                if (lane == 0) *next_slot = next;
+                if (next != LEANN_EMPTY) // in flight across the merge and barrier B3
+                    e_pref = (uint32_t)lane < deg ? adj_list(adj_base, upoff_p, deg, lv, cnode)[lane] : LEANN_EMPTY;
+            } else {
+                // ---- phase D (waves 1 .. NW-1): merge by rank into the other buffer ---------------------------------
+                // One work item per old entry (rank = index + #new keys below it) and per new key (rank = #old below it, by
+                // binary search, + #new below it); the scan over the new keys reads 16 B per LDS instruction, 8 keys per
+                // unrolled step, so the loads pipeline instead of paying one LDS latency per key.
+                const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(s.s_key);
+                for (uint32_t it = tid - 64; it < wsize + n_new; it += (NW - 1) * 64) {
+                    const bool isW = it < wsize;
+                    uint64_t k = isW ? Wc[it] : s.s_key[it - wsize];
+                    if (isW && it == sel) k |= 1ull;
+                    const uint64_t kk = k >> 1;
+                    uint32_t cnt = 0;
+#pragma unroll 4
+                    for (uint32_t j = 0; j < n_pad; j += 2) {
+                        const ulonglong2 v = kp[j >> 1];
+                        cnt += ((v.x >> 1) < kk) + ((v.y >> 1) < kk);
+                    }
+                    uint32_t rank = isW ? it + cnt : cnt;
+                    if (!isW) {
+                        uint32_t lo = 0, hi = wsize;
+                        while (lo < hi) {
+                            uint32_t mid = (lo + hi) >> 1;
+                            if ((Wc[mid] >> 1) < kk) lo = mid + 1; else hi = mid;
+                        }
+                        rank += lo;
+                    }
+                    if (rank < ef_l) Wn[rank] = k;
                 }
-                // first unexpanded entry of the new list: wave-level min, one LDS atomic per wave
-                cand = wave_min_u32(cand); // DPP ladder (common.cuh), not six ds_bpermute round trips
-                if (lane == 0 && cand != LEANN_EMPTY) atomicMin(next_slot, cand);
             }
             if (filt_level) {
                 // R <- kf best of R ∪ {allowed new keys}: the same merge by rank, on the blanked copy of the new keys.
@@ -559,9 +601,20 @@ __global__ void __launch_bounds__(NW * 64) beam_search_feat_filtered_kernel(Grap
     if (qi >= a.nq) return;
     beam_search_one<T, R, NW, true, true>(g, a, qi, smem);
 }
+// Throughput instantiation of the recompute-on search (4 waves per query, 520-B rows): the memory system delivers random 520-B rows at
+// no more than ~3.9 TB/s however many are in flight (scripts/micro/gather_bw.hip: 4.8 TB/s of 128-B lines; 3 KiB rows reach 6.4), and the
+// kernel gets closest to that with MANY queries per CU rather than many rows per wave: 8 workgroups per CU (the 16 KiB visited tables
+// allow 8) at 5 rows in flight per wave — a typical hop has ~24 unseen neighbours = 6 per wave — measured 3.14 M queries/s against 2.91 M
+// at 6 workgroups x 8 rows and 3.08 M at 7 x 6 (recompute10m_graph, ef = 56; scripts/exp/feat_occupancy.sh).
+#ifndef LEANN_FEAT_OCC
+#define LEANN_FEAT_OCC 8
+#endif
+#ifndef LEANN_FEAT_R1
+#define LEANN_FEAT_R1 5
+#endif
 // recompute-on instantiation: rows are bf16 features + inline norm, queries are W q
 template <int T, int R, int NW>
-__global__ void __launch_bounds__(NW * 64) beam_search_feat_kernel(GraphView g, SearchArgs a) {
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && T == 1) ? LEANN_FEAT_OCC : 1) beam_search_feat_kernel(GraphView g, SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t qi = blockIdx.x;
     if (qi >= a.nq) return;
