@@ -35,6 +35,13 @@ struct ListView {
     uint32_t *adjU; float *adjdU;  // [n_upper_lists x M]
     const uint32_t *upper_off;
     uint32_t M, M0;
+    // Vamana only: per-node PENDING back-edges (ids + distances, [n x P], compact, LEANN_EMPTY padded).  DiskANN lets a list grow to
+    // 1.3 R before it re-runs RobustPrune; lists here hold one id per lane of a wave (<= 64), so the slack lives beside the list:
+    // a back-edge that finds its target full waits here, invisible to searches, until P of them have gathered; then ONE RobustPrune
+    // over list + pending + proposals rewrites the list.  Every touched list being full, the strict rule pruned per proposal:
+    // ~600k prunes per 16k-point batch, each gathering 64+ rows (0.4 MB at 1536-d) — 67 % of a 10M x 1536 build.
+    uint32_t *pend; float *pendd;
+    uint32_t P;
 };
 __device__ __forceinline__ void list_ptr(const ListView &lv, uint32_t node, uint32_t level, uint32_t **ids, float **ds,
                                          uint32_t *cap) {
@@ -257,44 +264,55 @@ __global__ void __launch_bounds__(256) reverse_merge_kernel(const float *__restr
                                                             uint32_t level, const uint64_t *__restrict__ keys,
                                                             const uint32_t *__restrict__ srcs, uint32_t num,
                                                             const uint32_t *__restrict__ seg_start,
-                                                            const uint32_t *__restrict__ nseg_p, float alpha) {
+                                                            const uint32_t *__restrict__ nseg_p, float alpha, uint32_t flush_nodes) {
+    // flush_nodes != 0: final pass over nodes [0, flush_nodes) — fold whatever is still pending into its list (no proposals)
     __shared__ __attribute__((aligned(16))) float tri[TRI_ELEMS];
     __shared__ uint64_t skey[NCMAX];
     __shared__ uint32_t c_id[NCMAX];
     __shared__ float c_d[NCMAX];
     __shared__ uint32_t s_sel[64];
-    __shared__ uint32_t s_cnt, s_k, s_len;
-    const uint32_t nseg = *nseg_p;
+    __shared__ uint32_t s_cnt, s_k, s_len, s_pl;
+    const uint32_t nseg = flush_nodes ? flush_nodes : *nseg_p;
+    const uint32_t P = level == 0 ? lv.P : 0u;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint32_t start = seg_start[seg];
-        const uint32_t t = (uint32_t)(keys[start] >> 32);
+        const uint32_t start = flush_nodes ? 0u : seg_start[seg];
+        const uint32_t t = flush_nodes ? seg : (uint32_t)(keys[start] >> 32);
         uint32_t *ids; float *ds; uint32_t cap;
         list_ptr(lv, t, level, &ids, &ds, &cap);
-        if (threadIdx.x == 0) { s_k = 0; s_len = 0; }
+        uint32_t *pid = P ? lv.pend + (size_t)t * P : nullptr;
+        float *pdd = P ? lv.pendd + (size_t)t * P : nullptr;
+        if (threadIdx.x == 0) { s_k = 0; s_len = 0; s_pl = 0; }
         __syncthreads();
-        // proposals of this run (sorted by dist): count up to NCMAX; existing list length
-        if (threadIdx.x < NCMAX) {
+        // proposals of this run (sorted by dist): count up to NCMAX; existing list / pending lengths
+        if (!flush_nodes && threadIdx.x < NCMAX) {
             uint32_t i = start + threadIdx.x;
             if (i < num && (uint32_t)(keys[i] >> 32) == t) atomicAdd(&s_k, 1u); // run is contiguous
         }
         if (threadIdx.x < cap && ids[threadIdx.x] != LEANN_EMPTY) atomicAdd(&s_len, 1u); // lists are compact
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + P && pid[threadIdx.x - 64] != LEANN_EMPTY) atomicAdd(&s_pl, 1u);
         __syncthreads();
-        const uint32_t len = s_len;
+        const uint32_t len = s_len, pl = s_pl;
         uint32_t k = s_k;
-        if (len + k <= cap) { // room: append in (dist, src) order
+        if (flush_nodes && pl == 0) { __syncthreads(); continue; }
+        const uint32_t room = cap - len;
+        if (!flush_nodes && k <= room + (P - pl)) {
+            // room in the list (visible at once, closest proposals first), then in the pending area: plain appends in (dist, src) order
             for (uint32_t j = threadIdx.x; j < k; j += 256) {
-                ids[len + j] = srcs[start + j];
-                ds[len + j] = orderable_f32((uint32_t)keys[start + j]);
+                const uint32_t src = srcs[start + j];
+                const float dj = orderable_f32((uint32_t)keys[start + j]);
+                if (j < room) { ids[len + j] = src; ds[len + j] = dj; }
+                else { pid[pl + j - room] = src; pdd[pl + j - room] = dj; }
             }
             __syncthreads();
             continue;
         }
-        if (len + k > NCMAX) k = NCMAX - len; // keep the closest proposals only
-        const uint32_t nc = len + k;
+        if (len + pl + k > NCMAX) k = NCMAX - len - pl; // keep the closest proposals only
+        const uint32_t nc = len + pl + k;
         for (uint32_t i = threadIdx.x; i < NCMAX; i += 256) {
             uint64_t key = ~0ull;
             if (i < len) key = ((uint64_t)f32_orderable(ds[i]) << 32) | ids[i];
-            else if (i < nc) key = ((uint64_t)(uint32_t)keys[start + i - len] << 32) | srcs[start + i - len];
+            else if (i < len + pl) key = ((uint64_t)f32_orderable(pdd[i - len]) << 32) | pid[i - len];
+            else if (i < nc) key = ((uint64_t)(uint32_t)keys[start + i - len - pl] << 32) | srcs[start + i - len - pl];
             skey[i] = key;
         }
         // bitonic sort of NCMAX keys by (dist, id)
@@ -326,6 +344,7 @@ __global__ void __launch_bounds__(256) reverse_merge_kernel(const float *__restr
                 ds[j] = 0.f;
             }
         }
+        for (uint32_t j = threadIdx.x; j < P; j += 256) { pid[j] = LEANN_EMPTY; pdd[j] = 0.f; }
         __syncthreads();
     }
 }
@@ -383,6 +402,7 @@ struct Builder {
     leann_backend *h;
     ListView lv{};
     float *adjd0 = nullptr, *adjdU = nullptr;
+    uint32_t *pend = nullptr; float *pendd = nullptr; // Vamana: pending back-edges (ListView)
     std::vector<uint8_t> levels;     // host copy
     std::vector<uint32_t> upper_off; // host copy
     uint32_t *d_order = nullptr;     // insertion order (device copy)
@@ -402,7 +422,7 @@ struct Builder {
     ~Builder() { // every exit of build_on_device, including the error returns, releases the scratch and the stream
         if (st) (void)hipStreamSynchronize(st);
         void *ps[] = {cand_keys, cand_d, cand_cnt, candU_keys, candU_d, candU_cnt, d_rowsU, prop_key, prop_key2,
-                      prop_src, prop_src2, seg_start, nseg, cub_tmp, d_order, adjd0, adjdU, exp_keys, exp_cnt};
+                      prop_src, prop_src2, seg_start, nseg, cub_tmp, d_order, adjd0, adjdU, exp_keys, exp_cnt, pend, pendd};
         for (void *p : ps) (void)hipFree(p);
         if (st) (void)hipStreamDestroy(st);
     }
@@ -435,7 +455,7 @@ static int link_level(Builder &b, const uint32_t *d_rows, uint32_t nq, uint32_t 
     hipLaunchKernelGGL(segment_heads_kernel, dim3((num + 255) / 256), dim3(256), 0, b.st, b.prop_key2, num, b.seg_start, b.nseg);
     uint32_t grid = std::min<uint32_t>(num, 256 * 16);
     hipLaunchKernelGGL(reverse_merge_kernel, dim3(grid), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, level, b.prop_key2,
-                       b.prop_src2, num, b.seg_start, b.nseg, alpha);
+                       b.prop_src2, num, b.seg_start, b.nseg, alpha, 0u);
     BCHECK(hipGetLastError());
     return LEANN_OK;
 }
@@ -596,6 +616,18 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
     BCHECK(hipMemset(b.adjdU, 0, nu * h->g.M * 4));
     b.lv.adjd0 = b.adjd0;
     b.lv.adjdU = b.adjdU;
+    if (h->kind == LEANN_BACKEND_DISKANN) { // slack of DiskANN's 1.3 R, kept beside the 64-slot lists (see ListView)
+        static const uint32_t slack = [] { const char *e = getenv("LEANN_VAMANA_PENDING"); int v = e ? atoi(e) : 16; return (uint32_t)(v >= 0 && v <= 32 ? v : 16); }();
+        b.lv.P = slack;
+        if (slack) {
+            BCHECK(hipMalloc((void **)&b.pend, std::max<size_t>(n, 1) * slack * 4));
+            BCHECK(hipMalloc((void **)&b.pendd, std::max<size_t>(n, 1) * slack * 4));
+            BCHECK(hipMemset(b.pend, 0xFF, std::max<size_t>(n, 1) * slack * 4));
+            BCHECK(hipMemset(b.pendd, 0, std::max<size_t>(n, 1) * slack * 4));
+            b.lv.pend = b.pend;
+            b.lv.pendd = b.pendd;
+        }
+    }
     b.levels.resize(std::max<size_t>(n, 1));
     BCHECK(hipMemcpy(b.levels.data(), h->d_levels, n, hipMemcpyDeviceToHost));
     BCHECK(hipMalloc((void **)&b.d_order, std::max<size_t>(n, 1) * 4));
@@ -638,6 +670,13 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
     size_t bmax = bmax_hint ? bmax_hint : 16384;
     rc = builder_alloc_scratch(b, bmax);
     if (rc == LEANN_OK) rc = builder_insert_range(b, {}, s0, n);
+    if (rc == LEANN_OK && b.lv.P && n) { // fold what is still pending into the lists (DiskANN's final trim)
+        const float alpha = h->alpha;
+        hipLaunchKernelGGL(reverse_merge_kernel, dim3(256 * 16), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, 0u, (const uint64_t *)nullptr,
+                           (const uint32_t *)nullptr, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, alpha, (uint32_t)n);
+        BCHECK(hipGetLastError());
+        BCHECK(hipStreamSynchronize(b.st));
+    }
     return rc; // ~Builder: stream synchronised, scratch freed
 }
 

@@ -304,3 +304,23 @@ def test_coalescing_can_be_reconfigured_while_searches_are_in_flight(la, po, gpu
     assert not fl.is_alive() and not bad
     s.set_coalescing(0, 0)
     s.close()
+
+
+def test_recycled_scratch_is_never_read_before_it_is_written(la, po, gpu):
+    """DESIGN.md §7 (the hipMallocAsync episode): scratch blocks of the exact scan come back from a free list with their previous
+    contents.  Alternate calls of very different shapes — every later call sees blocks dirtied by a different problem — and check
+    each against the oracle: a read of a word not written in the same call would surface here as a wrong key."""
+    d = 96
+    X = synth(po, 70_000, d)
+    dX = la.DeviceArray.from_host(X)
+    shapes = [(70_000, 64, 10), (3_000, 3, 2), (66_000, 17, 64), (2_049, 1, 1), (70_000, 5, 100), (4_100, 64, 10), (70_000, 64, 10)]
+    for n, nq, k in shapes:
+        Q = synth(po, nq, d, stream=1, i0=n)
+        dQ = la.DeviceArray.from_host(Q)
+        dk, ds, dc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+        la._native.check(la.lib().leann_scan_topk_device(dX.ptr, n, d, d, dQ.ptr, nq, k, None, 0, dk.ptr, ds.ptr, dc.ptr, None))
+        la.sync()
+        gk, gs = dk.to_host(), ds.to_host()
+        for i in range(0, nq, max(1, nq // 4)):
+            k0, s0 = po.scan_topk(X[:n], Q[i], k, mode=1)
+            assert (gk[i] == k0).all() and (gs[i] == s0).all(), (n, nq, k, i)
