@@ -11,7 +11,7 @@ HDRS     := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) include/leann_back
 HOST     := leann-rs_amd/host
 CXXFLAGS := -O2 -std=c++17 -ffp-contract=off -Wall -Wextra -Wno-unused-parameter
 
-all: $(CSRC)/libleann_hip.so oracle $(HOST)/leann $(HOST)/host_selftest
+all: $(CSRC)/libleann_hip.so oracle $(HOST)/leann $(HOST)/host_selftest $(HOST)/host_selftest_asan
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -26,11 +26,17 @@ $(HOST)/leann: $(HOST)/leann_cli.cpp $(HOST)/leann_host.hpp $(HOST)/json.hpp inc
 $(HOST)/host_selftest: $(HOST)/host_selftest.cpp $(HOST)/leann_host.hpp $(HOST)/json.hpp include/leann_backend.h $(CSRC)/libleann_hip.so
 	g++ $(CXXFLAGS) -o $@ $(HOST)/host_selftest.cpp -L$(CSRC) -lleann_hip -Wl,-rpath,'$$ORIGIN/../csrc' -Wl,-rpath,/opt/rocm/lib
 
+# the host C++ (JSON parser, passage store, BM25, filters, search_with_options assembly) under AddressSanitizer + UBSan — CPU only
+# (GPU sanitizers are not available on this pool); tests/test_cpu_host.py runs it over the same fixtures as the plain build
+$(HOST)/host_selftest_asan: $(HOST)/host_selftest.cpp $(HOST)/leann_host.hpp $(HOST)/json.hpp include/leann_backend.h $(CSRC)/libleann_hip.so
+	g++ -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -o $@ \
+	    $(HOST)/host_selftest.cpp -L$(CSRC) -lleann_hip -Wl,-rpath,'$$ORIGIN/../csrc' -Wl,-rpath,/opt/rocm/lib
+
 oracle:
 	$(MAKE) -s -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o $(CSRC)/*.so $(HOST)/leann $(HOST)/host_selftest
+	rm -f $(CSRC)/*.o $(CSRC)/*.so $(HOST)/leann $(HOST)/host_selftest $(HOST)/host_selftest_asan
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -23,7 +23,7 @@ struct SearchArgs {
     float hybrid_alpha = 0.7f;
     std::string format = "text";
     std::optional<std::string> query_prompt_template, embedding_mode, query_vector_file;
-    std::string device = "0";
+    std::string device = getenv("LEANN_DEVICES") ? getenv("LEANN_DEVICES") : "0"; // "0", or a list / range = sharded (leann_backend.h)
     bool device_filter = false;
 };
 
@@ -45,7 +45,7 @@ static void usage_search() {
          "      --query-prompt-template <T>    Query prompt template prefix for asymmetric embedding models\n"
          "      --embedding-mode <MODE>        (additive) override the index's embedding mode; `synthetic` works offline\n"
          "      --query-vector-file <FILE>     (additive) raw f32 query embedding instead of embedding the query text\n"
-         "      --device <N>                   (additive) HIP device ordinal [default: 0]\n"
+         "      --device <SPEC>                (additive) HIP device ordinal, or a list / range (\"0-7\") = index sharded over several GPUs [env: LEANN_DEVICES] [default: 0]\n"
          "      --device-filter                (additive) evaluate --filter inside the GPU traversal instead of 5x over-fetch + post-filter\n"
          "  -h, --help                         Print help");
 }

@@ -86,3 +86,27 @@ def test_cpp_assemble_results_matches_the_fixture(tmp_path):
     out = json.loads(subprocess.check_output([exe, str(p)]))
     for c, got in zip(FX["cases"], out["searcher"]):
         assert [(i, f32(s)) for i, s in got] == [(i, f32(s)) for i, s in c["expect"]], c["name"]
+
+
+def test_host_cpp_is_clean_under_asan_and_ubsan(tmp_path):
+    """the same fixtures through the AddressSanitizer + UBSan build of the host C++ (JSON parser, passage store, tokenizer, BM25,
+    hybrid_rerank, metadata filters, assemble_results): identical output, no sanitizer report.  (CPU only; VERDICT r1 aux note.)"""
+    exe = os.path.join(HOST, "host_selftest_asan")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", ROOT, "leann-rs_amd/host/host_selftest_asan"])
+    stem = write_reference_layout(str(tmp_path / "idx"), FX["corpus"])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_formulas.json")))
+    filters = [dict(filter=f, metadata=m) for f, m in (("source:*.rs", {"source": "a.rs"}), ("lines>=10,lang=rust", {"lines": 12, "lang": "rust"}),
+                                                       ("t in [a,b,c]", {"t": "b"}), ("x.y~zz", {"x": {"y": "azzb"}}), ("bad filter", {}), ("q?", {}))]
+    cases = dict(tokenize=gold["tokenize"], bm25=gold["bm25"], hybrid_rerank=gold["hybrid_rerank"], filters=filters,
+                 synthetic_embed="hello sanitizer world", searcher=dict(index_path=stem, cases=FX["cases"]))
+    p = tmp_path / "cases.json"
+    p.write_text(json.dumps(cases))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([exe, str(p)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    out = json.loads(r.stdout)
+    for c, got in zip(FX["cases"], out["searcher"]):
+        assert [(i, f32(s)) for i, s in got] == [(i, f32(s)) for i, s in c["expect"]], c["name"]
+    assert out["filters"][:4] == [True, True, True, True]
