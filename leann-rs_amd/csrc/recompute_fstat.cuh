@@ -146,6 +146,9 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
 // Candidate emission (chunks after the first): CandEmit, internal.h.
 #define FSTAT_MAX_QUERIES 256 // queries per launch: the encode GEMM is shared, each 32-query tile adds one G sub-slice per unit
 #define LEANN_FSTAT_RB 2 // 32-passage blocks per wave (the per-k-step asm statements are written for two)
+#ifndef LEANN_FSTAT_PFD
+#define LEANN_FSTAT_PFD 0 // k-steps between a feature fragment's last MFMA and its refill for the next unit (experiment knob)
+#endif
 // Fragment-major copy of the features for fused_fstat_kernel: Ft[block of 32 rows][k-step][lane = lh * 32 + row][8 bf16], i.e.
 // the 1 KiB a wave loads per (block, k-step) is contiguous (8 full lines per instruction instead of 32 quarter lines of a
 // row-major read: the row-major form costs ~170 issue cycles per load next to the MFMAs).  Rows are padded to whole units.
@@ -433,8 +436,13 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                         } else {
                             FSTAT_GK_T0(sc[0], sc[1], s0, s1, s2, a[0][ks], a[1][ks], waddr, goff, dsb[dt], dld[dt], doff);
                         }
-                        if constexpr (PF) load_features(a, nprow0, ks);
+                        // refill for the next unit, LEANN_FSTAT_PFD k-steps behind the fragment's last MFMA
+                        if constexpr (PF && ks >= LEANN_FSTAT_PFD) load_features(a, nprow0, ks - LEANN_FSTAT_PFD);
                     });
+                    if constexpr (PF)
+                        static_for<LEANN_FSTAT_PFD>([&a, &nprow0, &load_features](auto kc) __attribute__((always_inline)) {
+                            load_features(a, nprow0, KS - LEANN_FSTAT_PFD + decltype(kc)::value);
+                        });
                 };
                 g_loop(std::integral_constant<bool, KIND == 2>{});
                 asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1])); // as above: no reader of the score tiles above the pad
