@@ -360,7 +360,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_shard = os.environ.get("LEANN_BENCH_FORCE_SHARD") == "1" and "RANK" in os.environ  # rehearsal: the N > 1 code path with one rank
+    if world > 1 or force_shard:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend_name = os.environ.get("LEANN_BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
@@ -388,7 +389,7 @@ def main():
     backend = wl.get("backend", 0)
     k, B = args.k, args.batch
     ld = (d + 3) // 4 * 4
-    shard = world > 1 and args.mode == "shard"
+    shard = (world > 1 or force_shard) and args.mode == "shard"
     row0 = rank * rows if shard else 0
     corpus_total = rows * world if shard else rows
     stream = torch.cuda.Stream(device=dev)

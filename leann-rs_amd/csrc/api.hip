@@ -133,6 +133,11 @@ static int ensure_gpool(leann_backend *h) {
         if (hipMemset(p2, 0, ((size_t)tables2 << bits2) * 8) != hipSuccess) return fail("hipMemset");
         if (hipMemset(lock2, 0, tables2 * 4) != hipSuccess) return fail("hipMemset");
     }
+    // hipMemset on device memory returns before the fill has run (it is queued on the null stream), and searches run on NON-BLOCKING
+    // streams, which do not wait for the null stream: without this wait the first launch could migrate queries into a table that was
+    // still being zeroed under them (entries lost -> nodes visited twice -> results off the oracle's; seen once the migration came a
+    // few microseconds earlier, tests/test_gpu_parity.py::test_visited_table_overflow_moves_to_hbm_pool).  Once per handle.
+    if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize");
     h->gpool_lock = lock;
     h->gpool_ctr = lock + tables;
     h->gpool_bits = bits;
@@ -886,6 +891,7 @@ int leann_internal_from_host(int backend, size_t n, size_t dims, uint32_t M, uin
             (n_upper_lists && hipMemcpy((void *)h->g.adjU, adjU, n_upper_lists * M * 4, hipMemcpyHostToDevice) != hipSuccess))
             return fail("upload of the graph arrays");
     }
+    if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize"); // the fills above are null-stream work; searches run on non-blocking streams
     *out = h;
     return LEANN_OK;
 }
