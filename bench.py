@@ -329,11 +329,11 @@ def main():
     ap.add_argument("--workload", default="hnsw10m", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="shard", choices=["shard", "replica"])
     ap.add_argument("--batch", type=int, default=16384, help="queries per step (per rank in replica mode)")
-    ap.add_argument("--ef", default="auto", help="beam width: 'auto' (default) = smallest of 48..128 whose measured "
+    ap.add_argument("--ef", default="auto", help="beam width: 'auto' (default) = smallest of 40..128 whose measured "
                     "recall@10 is >= 0.955 on the recall queries (the metric's operating point is defined by recall >= 0.95); "
                     "a number = fixed (BASELINE configs[1] names ef=128); 0 = the workload's named value")
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--recall-queries", type=int, default=4000, help="queries with exact ground truth: the first half picks --ef auto, the second half reports recall")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency / 64-caller section")
     ap.add_argument("--cpu-queries", type=int, default=16384)
@@ -550,13 +550,17 @@ def main():
     # recall that goes into the record is measured on the OTHER half (disjoint queries: no tuning on the reported set)
     half = nrq // 2 if ef_auto and nrq >= 200 else 0
     if ef_auto and not (allow is not None and args.filter_exact):
-        for cand in (40, 48, 56, 64, 72, 80, 96, 112, 128):
+        for cand in (40, 44, 48, 52, 56, 60, 64, 72, 80, 96, 112, 128):
             ef = cand
             if measure_recall(0, half or nrq) >= 0.955:
                 break
         log(f"--ef auto picked ef={ef} on recall queries [0, {half or nrq})")
     recall = measure_recall(half, nrq)
-    log(f"recall@{k} = {recall:.4f} at ef={ef} (recall queries [{half}, {nrq}), corpus {corpus_total} x {d})")
+    bumped = False
+    while ef_auto and half and recall < 0.95 and ef < 128:  # guard only: the metric is defined at recall >= 0.95 on the REPORTED queries
+        ef = min(128, ef + (4 if ef < 64 else 8))
+        recall, bumped = measure_recall(half, nrq), True
+    log(f"recall@{k} = {recall:.4f} at ef={ef} (recall queries [{half}, {nrq}), corpus {corpus_total} x {d})" + (" [ef raised after the report-half check]" if bumped else ""))
 
     # ---- warmup, then exactly K timed steps between barrier + synchronize -------------------------
     for w in range(args.warmup):
@@ -670,7 +674,8 @@ def main():
         out["config"]["value_unit_note"] = (f"value = end-to-end queries/s over the {corpus_total}-row corpus (every query searched on all "
                                             f"{world} shards, lists all-gathered over {'RCCL inside the library' if rccl else dist.get_backend()}, merged on every rank); "
                                             "shard_searches_per_s = value x n_gpus")
-    out["config"]["recall_protocol"] = (f"ef picked on recall queries [0, {half}), recall reported on [{half}, {nrq})" if half else
+    out["config"]["recall_protocol"] = (f"ef picked on recall queries [0, {half}) (smallest of the ladder with recall >= 0.955), recall reported on [{half}, {nrq})"
+                                        + (" — ef then raised until the reported half reached 0.95" if bumped else "") if half else
                                         f"fixed ef; recall on {nrq} queries")
 
     # ---- PCIe-inclusive rate: the same batch through the host-pointer entry point (queries and results in host memory) ----
