@@ -223,8 +223,8 @@ static int launch_one(K kernel, int nthreads, size_t lds, const GraphView &g, co
     HIP_CHECK_RET(hipGetLastError());
     return LEANN_OK;
 }
-static int search_lds_checked(const GraphView &g, const SearchArgs &a, size_t *lds) {
-    *lds = search_lds_bytes(a.ef, std::max(g.M0, g.M), a.hash_bits, a.allow ? a.k : 0u);
+static int search_lds_checked(const GraphView &g, const SearchArgs &a, size_t *lds, int nw) {
+    *lds = search_lds_bytes(a.ef, std::max(g.M0, g.M), a.hash_bits, a.allow ? a.k : 0u, nw > 4 ? 2u : 1u);
     if (*lds > 160 * 1024) {
         leann_set_error("search: complexity %u needs %zu B of LDS per query (> 160 KiB)", a.ef, *lds);
         return LEANN_ERR_INVALID;
@@ -235,7 +235,7 @@ static int search_lds_checked(const GraphView &g, const SearchArgs &a, size_t *l
 template <int T, int R, int NW>
 static int launch_search_NW(const GraphView &g, const SearchArgs &a, hipStream_t st) {
     size_t lds;
-    if (int rc = search_lds_checked(g, a, &lds)) return rc;
+    if (int rc = search_lds_checked(g, a, &lds, NW)) return rc;
     if (a.allow) return launch_one(beam_search_filtered_kernel<T, R, NW>, NW * 64, lds, g, a, st);
     if (a.q_rows) return launch_one(beam_search_kernel<T, R, NW, true>, NW * 64, lds, g, a, st);
     return launch_one(beam_search_kernel<T, R, NW, false>, NW * 64, lds, g, a, st);
@@ -256,7 +256,7 @@ static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t 
 template <int T, int R>
 static int launch_search_feat(const GraphView &g, const SearchArgs &a, hipStream_t st) {
     size_t lds;
-    if (int rc = search_lds_checked(g, a, &lds)) return rc;
+    if (int rc = search_lds_checked(g, a, &lds, a.nq <= 512 ? 16 : 4)) return rc;
     if (a.nq <= 512) {
         if (a.allow) return launch_one(beam_search_feat_filtered_kernel<T, R, 16>, 16 * 64, lds, g, a, st);
         return launch_one(beam_search_feat_kernel<T, R, 16>, 16 * 64, lds, g, a, st);

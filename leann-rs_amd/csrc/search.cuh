@@ -168,19 +168,22 @@ __device__ __forceinline__ const uint32_t *adj_list(const uint32_t *__restrict__
     return base + list * deg;
 }
 
-// LDS carve-up (dynamic): [W0 | W1 | s_key | s_new | misc | (filtered: R0 | R1 | s_keyR) | table]
+// LDS carve-up (dynamic): [W0 | W1 | s_key x2 | s_new x2 | misc | (filtered: R0 | R1 | s_keyR x2) | table]
+// s_key / s_new / s_keyR exist once per hop parity: wave 0 prepares hop h + 1 (adjacency list through the visited table) while the
+// other waves still merge hop h.
 struct SearchLds {
     uint64_t *s_key;
     uint32_t *s_new;
-    uint32_t *misc;  // [0]=n_new [1],[2]=next selection (double buffered) [3]=table full [4]=pool slot [5]=generation
-                     // [6]=1 if the target level's seed is allowed (filtered)
+    uint32_t *misc;  // [1],[2]=next selection (by hop parity) [3]=table full [4]=pool slot [5]=generation
+                     // [6]=1 if the target level's seed is allowed (filtered) [8],[9]=n_new (by hop parity)
 };
 // kf = result-list length of a filtered search (0: unfiltered)
-__host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits, uint32_t kf = 0) {
+// nbuf = 2 for the latency form of the hop loop (NW > 4: s_key / s_new / s_keyR per hop parity), 1 for the throughput form
+__host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg, uint32_t hash_bits, uint32_t kf = 0, uint32_t nbuf = 2) {
     size_t efp = (ef + 1) & ~1u;
-    size_t b = 2 * efp * 8 + ((size_t)maxdeg + 8) * 8 + (size_t)maxdeg * 4 + 16 * 4; // s_key carries 8 sentinel slots
+    size_t b = 2 * efp * 8 + nbuf * ((size_t)maxdeg + 8) * 8 + nbuf * (size_t)maxdeg * 4 + 16 * 4; // s_key carries 8 sentinel slots
     b = (b + 15) & ~(size_t)15;
-    if (kf) b += 2 * (size_t)((kf + 1) & ~1u) * 8 + ((size_t)maxdeg + 8) * 8;
+    if (kf) b += 2 * (size_t)((kf + 1) & ~1u) * 8 + nbuf * ((size_t)maxdeg + 8) * 8;
     return b + ((size_t)1 << hash_bits) * 4;
 }
 
@@ -192,10 +195,12 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     const uint32_t efp = (ef + 1) & ~1u;
     SearchLds s;
     uint64_t *const W0 = reinterpret_cast<uint64_t *>(smem); // buffer b lives at W0 + b*efp (no pointer array: stays out of scratch)
+    constexpr uint32_t NBUF = NW > 4 ? 2u : 1u; // latency form of the hop loop: per-parity buffers (search_lds_bytes)
+    const uint32_t kstride = maxdeg + 8;
     s.s_key = W0 + 2 * efp;
-    s.s_new = reinterpret_cast<uint32_t *>(s.s_key + maxdeg + 8);
-    s.misc = s.s_new + maxdeg;
-    size_t off = 2 * (size_t)efp * 8 + ((size_t)maxdeg + 8) * 8 + (size_t)maxdeg * 4 + 64;
+    s.s_new = reinterpret_cast<uint32_t *>(s.s_key + NBUF * kstride);
+    s.misc = s.s_new + NBUF * maxdeg;
+    size_t off = 2 * (size_t)efp * 8 + NBUF * ((size_t)maxdeg + 8) * 8 + NBUF * (size_t)maxdeg * 4 + 64;
     off = (off + 15) & ~(size_t)15;
     // filtered: R list (k best allowed keys so far, double buffered) + the new keys with disallowed ones blanked
     const uint32_t kf = FILT ? a.k : 0u, kfp = (kf + 1) & ~1u;
@@ -204,7 +209,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     const uint8_t *const allow = FILT ? a.allow + (size_t)qi * a.allow_stride : nullptr;
     uint32_t rsize = 0;
     int rcur = 0;
-    if (FILT) off += 2 * (size_t)kfp * 8 + ((size_t)maxdeg + 8) * 8;
+    if (FILT) off += 2 * (size_t)kfp * 8 + NBUF * ((size_t)maxdeg + 8) * 8;
     uint32_t *table = reinterpret_cast<uint32_t *>(smem + off);
     const uint32_t hbits = a.hash_bits, hsize = 1u << hbits;
     uint32_t vis_limit = hsize - (hsize >> 2); // 75 % load
@@ -275,250 +280,513 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         n_vis = 1;
         uint32_t sel = 0;
         uint32_t hop = 0;
-        // Adjacency list of the NEXT node to expand, one neighbour id per lane of wave 0 (lists hold at most 64 ids).  The load is
-        // issued as soon as the next candidate is known — right after the new distances exist, BEFORE the merge (phase E below) —
-        // so its HBM round trip runs under the merge and the barrier instead of at the head of the next hop.
-        uint32_t e_pref = LEANN_EMPTY;
-        // (level-dependent pieces of the list address as VALUES: selecting between the two struct members by address makes hipcc keep
-        // the by-value GraphView in scratch memory)
-        const uint32_t *const adj_base = lv == 0 ? adj0_p : adjU_p;
-        if (wave == 0) e_pref = (uint32_t)lane < deg ? adj_list(adj_base, upoff_p, deg, lv, key_id(best))[lane] : LEANN_EMPTY;
-        while (sel != LEANN_EMPTY) {
-            uint64_t *Wc = W0 + cur * efp, *Wn = W0 + (cur ^ 1) * efp;
-#ifdef LEANN_STAMPS // diagnostic build only (scripts/stamps.sh): where does a hop spend its cycles?
-            const uint64_t st0 = __builtin_amdgcn_s_memtime();
-#endif
-            // ---- phase B: adjacency list through the visited table (wave 0) ------------------
-            if (wave == 0) {
-                const uint32_t node = key_id(Wc[sel]);
-                if (a.out_expanded && lv == (int)a.target_level && lane == 0 && hop < a.exp_cap)
-                    a.out_expanded[(size_t)qi * a.exp_cap + hop] = ((Wc[sel] >> 32) << 32) | node;
+        // Two forms of the hop loop (identical results: exactly one candidate is expanded per step, in the sequential order).
+        // Throughput form (4 waves per query, every CU full): phase B — the adjacency list through the visited table, wave 0 — at the
+        // head of the hop, three barriers; its list was prefetched by phase E of the hop before.  Latency form (16 waves per query,
+        // batches <= 512): wave 0 runs phase B of hop h + 1 right behind phase E, UNDER the merge of hop h — two barriers per hop, single
+        // query 0.365 -> 0.32 ms.  With the chip saturated the adjacency round trip outlasts the merge either way and the leaner wave 0
+        // of the throughput form is faster (recompute-on search: 3.05 against 2.98 M queries/s; hnsw10m equal; scripts/exp/ab.sh).
+        constexpr bool EARLY_B = NW > 4;
+        if constexpr (!EARLY_B) {
+            // Adjacency list of the NEXT node to expand, one neighbour id per lane of wave 0 (lists hold at most 64 ids).  The load is
+            // issued as soon as the next candidate is known — right after the new distances exist, BEFORE the merge (phase E below) —
+            // so its HBM round trip runs under the merge and the barrier instead of at the head of the next hop.
+            uint32_t e_pref = LEANN_EMPTY;
+            // (level-dependent pieces of the list address as VALUES: selecting between the two struct members by address makes hipcc keep
+            // the by-value GraphView in scratch memory)
+            const uint32_t *const adj_base = lv == 0 ? adj0_p : adjU_p;
+            if (wave == 0) e_pref = (uint32_t)lane < deg ? adj_list(adj_base, upoff_p, deg, lv, key_id(best))[lane] : LEANN_EMPTY;
+            while (sel != LEANN_EMPTY) {
+                uint64_t *Wc = W0 + cur * efp, *Wn = W0 + (cur ^ 1) * efp;
+    #ifdef LEANN_STAMPS // diagnostic build only (scripts/stamps.sh): where does a hop spend its cycles?
+                const uint64_t st0 = __builtin_amdgcn_s_memtime();
+    #endif
+                // ---- phase B: adjacency list through the visited table (wave 0) ------------------
+                if (wave == 0) {
+                    const uint32_t node = key_id(Wc[sel]);
+                    if (a.out_expanded && lv == (int)a.target_level && lane == 0 && hop < a.exp_cap)
+                        a.out_expanded[(size_t)qi * a.exp_cap + hop] = ((Wc[sel] >> 32) << 32) | node;
+                    uint32_t n_new = 0;
+                    bool ovf = (n_vis + deg > vis_limit);
+                    if (!ovf) {
+                        const uint32_t e = e_pref; // this node's list (a hop redone after a table migration reads the same register again)
+                        bool isnew = false;
+                        if (e != LEANN_EMPTY) isnew = hbm ? vis_insert_hbm(gtab, gbits, gen, e) : vis_insert_lds(table, hbits, e);
+                        unsigned long long m = __ballot(isnew);
+                        uint32_t pos = __popcll(m & ((1ull << lane) - 1ull));
+                        if (isnew) s.s_new[pos] = e;
+                        n_new = __popcll(m);
+                    }
+                    n_vis += n_new;
+                    n_evals += n_new;
+                    if (!ovf) { if (lv == 0) hops0++; else hopsU++; }
+                    if (lane < 8) s.s_key[n_new + lane] = ~0ull; // sentinels: the merge scans keys 8 at a time
+                    if (filt_level && lane < 8) s_keyR[n_new + lane] = ~0ull;
+                    if (lane == 0) {
+                        s.misc[0] = n_new;
+                        if (ovf) s.misc[3] = 1;
+                    }
+                }
+    #ifdef LEANN_STAMPS
+                const uint64_t stB = __builtin_amdgcn_s_memtime();
+    #endif
+                __syncthreads(); // B1
+    #ifdef LEANN_STAMPS
+                const uint64_t stB1 = __builtin_amdgcn_s_memtime();
+    #endif
+                const uint32_t table_full = s.misc[3];
+                if (table_full) {
+                    // Table full: move the visited set one level up (LDS -> pool 1 -> pool 2) and redo this hop.
+                    const uint32_t next = hbm + 1;
+                    if (next > 2 || (next == 2 && !a.gpool2)) { aborted = true; break; } // defensive: see the pool comment above
+                    __syncthreads(); // every thread has read the flag before it is cleared
+                    if (tid == 0) {
+                        uint32_t *locks = next == 1 ? a.gpool_lock : a.gpool2_lock;
+                        const uint32_t ntab = next == 1 ? a.gpool_tables : a.gpool2_tables;
+                        uint32_t t = atomicAdd(&a.gpool_ctr[next == 1 ? 0 : 2], 1u), slot;
+                        for (uint32_t i = 0;; i++) { // holders never wait for anything, so a table always comes free
+                            slot = (t + i) % ntab;
+                            if (atomicCAS(&locks[slot], 0u, 1u) == 0u) break;
+                            if ((i % ntab) == ntab - 1) __builtin_amdgcn_s_sleep(32);
+                        }
+                        s.misc[4] = slot;
+                        if (!hbm) s.misc[5] = atomicAdd(&a.gpool_ctr[1], 1u) + 1u; // pool 1 -> 2 keeps the generation
+                        s.misc[3] = 0;
+                    }
+                    __syncthreads();
+                    const uint32_t nslot = s.misc[4];
+                    const uint32_t nbits = next == 1 ? a.gpool_bits : a.gpool2_bits;
+                    unsigned long long *ntab_p = (next == 1 ? a.gpool : a.gpool2) + ((size_t)nslot << nbits);
+                    if (!hbm) {
+                        gen = s.misc[5];
+                        for (uint32_t i = tid; i < hsize; i += NW * 64) {
+                            uint32_t e = table[i];
+                            if (e != LEANN_EMPTY) vis_insert_hbm(ntab_p, nbits, gen, e);
+                        }
+                    } else {
+                        for (uint32_t i = tid; i < (1u << gbits); i += NW * 64) {
+                            const unsigned long long cur = __hip_atomic_load(&gtab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((uint32_t)(cur >> 32) == gen) vis_insert_hbm(ntab_p, nbits, gen, (uint32_t)cur);
+                        }
+                        __syncthreads(); // every probe of the old table has returned
+                        if (tid == 0) atomicExch(&a.gpool_lock[gslot], 0u);
+                    }
+                    gtab = ntab_p;
+                    gbits = nbits;
+                    gslot = nslot;
+                    hbm = next;
+                    vis_limit = (1u << gbits) - (1u << (gbits - 2));
+                    __syncthreads();
+                    continue;
+                }
+                const uint32_t n_new = s.misc[0];
+                // ---- phase C: stream the new rows, R in flight per wave ------------------------------
+                for (uint32_t j0 = wave; j0 < n_new; j0 += NW * R) {
+                    uint32_t ids[R];
+                    float dd[R];
+                    int nrows = 0;
+    #pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        uint32_t j = j0 + r * NW;
+                        if (j < n_new) { ids[r] = s.s_new[j]; nrows = r + 1; }
+                    }
+                    uint32_t abyte = 0, abit = 0;
+                    if (filt_level && lane < R && j0 + lane * NW < n_new) { // lane r fetches row r's allow bit alongside the rows
+                        const uint32_t e = s.s_new[j0 + lane * NW];
+                        abyte = allow[e >> 3];
+                        abit = e & 7u;
+                    }
+                    if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd);
+                    else wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
+                    const unsigned long long amask = FILT ? __ballot((abyte >> abit) & 1u) : 0ull;
+                    if (lane == 0) {
+    #pragma unroll
+                        for (int r = 0; r < R; r++)
+                            if (r < nrows) {
+                                const uint64_t key = make_key(dd[r], ids[r]);
+                                s.s_key[j0 + r * NW] = key;
+                                if (filt_level) s_keyR[j0 + r * NW] = ((amask >> r) & 1ull) ? key : ~0ull;
+                            }
+                    }
+                }
+    #ifdef LEANN_STAMPS
+                const uint64_t stC = __builtin_amdgcn_s_memtime();
+    #endif
+                __syncthreads(); // B2
+    #ifdef LEANN_STAMPS
+                const uint64_t stB2 = __builtin_amdgcn_s_memtime();
+    #endif
+                // ---- phase E (wave 0): the next candidate, known before the merge -------------------------------------
+                // The merged beam's first unexpanded entry is the smaller of (a) the first unexpanded entry of the OLD beam other than
+                // the one just expanded and (b) the smallest new key; its index in the merged beam is the number of keys below it.
+                // Same entry, same index as a scan of the merged list would give — but available one merge earlier, so wave 0 issues
+                // the next hop's adjacency load now and the other waves merge meanwhile.
+                uint32_t *next_slot = &s.misc[1 + (hop & 1)];
+                const uint32_t n_pad = (n_new + 7) & ~7u;
+                if (wave == 0) {
+                    uint32_t u = LEANN_EMPTY;
+                    for (uint32_t base = 0; base < wsize && u == LEANN_EMPTY; base += 64) {
+                        const uint32_t i = base + lane;
+                        const unsigned long long m = __ballot(i < wsize && i != sel && !(Wc[i] & 1ull));
+                        if (m) u = base + (uint32_t)__ffsll((long long)m) - 1u;
+                    }
+                    const uint64_t c_old = u != LEANN_EMPTY ? Wc[u] : ~0ull;
+                    const uint64_t kj = (uint32_t)lane < n_new ? s.s_key[lane] : ~0ull; // n_new <= 64: one key per lane
+                    const uint32_t hi = wave_min_u32((uint32_t)(kj >> 32));
+                    const uint32_t lo = wave_min_u32((uint32_t)(kj >> 32) == hi ? (uint32_t)kj : 0xFFFFFFFFu);
+                    const uint64_t c_new = n_new ? (((uint64_t)hi << 32) | lo) : ~0ull;
+                    uint32_t next = LEANN_EMPTY, cnode = 0;
+                    if (c_old != ~0ull || c_new != ~0ull) {
+                        uint32_t rank;
+                        if ((c_old >> 1) < (c_new >> 1)) {
+                            rank = u + (uint32_t)__popcll(__ballot((kj >> 1) < (c_old >> 1)));
+                            cnode = key_id(c_old);
+                        } else {
+                            rank = 0;
+                            for (uint32_t base = 0; base < wsize; base += 64) {
+                                const uint32_t i = base + lane;
+                                rank += (uint32_t)__popcll(__ballot(i < wsize && (Wc[i] >> 1) < (c_new >> 1)));
+                            }
+                            cnode = key_id(c_new);
+                        }
+                        if (rank < ef_l) next = rank;
+                    }
+                    if (lane == 0) *next_slot = next;
+                    if (next != LEANN_EMPTY) // in flight across the merge and barrier B3
+                        e_pref = (uint32_t)lane < deg ? adj_list(adj_base, upoff_p, deg, lv, cnode)[lane] : LEANN_EMPTY;
+                } else {
+                    // ---- phase D (waves 1 .. NW-1): merge by rank into the other buffer ---------------------------------
+                    // One work item per old entry (rank = index + #new keys below it) and per new key (rank = #old below it, by
+                    // binary search, + #new below it); the scan over the new keys reads 16 B per LDS instruction, 8 keys per
+                    // unrolled step, so the loads pipeline instead of paying one LDS latency per key.
+                    const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(s.s_key);
+                    for (uint32_t it = tid - 64; it < wsize + n_new; it += (NW - 1) * 64) {
+                        const bool isW = it < wsize;
+                        uint64_t k = isW ? Wc[it] : s.s_key[it - wsize];
+                        if (isW && it == sel) k |= 1ull;
+                        const uint64_t kk = k >> 1;
+                        uint32_t cnt = 0;
+    #pragma unroll 4
+                        for (uint32_t j = 0; j < n_pad; j += 2) {
+                            const ulonglong2 v = kp[j >> 1];
+                            cnt += ((v.x >> 1) < kk) + ((v.y >> 1) < kk);
+                        }
+                        uint32_t rank = isW ? it + cnt : cnt;
+                        if (!isW) {
+                            uint32_t lo = 0, hi = wsize;
+                            while (lo < hi) {
+                                uint32_t mid = (lo + hi) >> 1;
+                                if ((Wc[mid] >> 1) < kk) lo = mid + 1; else hi = mid;
+                            }
+                            rank += lo;
+                        }
+                        if (rank < ef_l) Wn[rank] = k;
+                    }
+                }
+                if (filt_level) {
+                    // R <- kf best of R ∪ {allowed new keys}: the same merge by rank, on the blanked copy of the new keys.
+                    // Skipped (uniformly) when no allowed new key beats the current kf-th.
+                    uint64_t *Rc = R0 + rcur * kfp, *Rn = R0 + (rcur ^ 1) * kfp;
+                    const uint64_t thr = rsize == kf ? Rc[kf - 1] : ~0ull;
+                    uint32_t n_in = 0;
+                    for (uint32_t j = 0; j < n_new; j += 64) n_in += __popcll(__ballot(j + lane < n_new && s_keyR[j + lane] < thr));
+                    if (n_in) {
+                        const ulonglong2 *kr = reinterpret_cast<const ulonglong2 *>(s_keyR);
+                        for (uint32_t it = tid; it < rsize + n_new; it += NW * 64) {
+                            const bool isR = it < rsize;
+                            const uint64_t k = isR ? Rc[it] : s_keyR[it - rsize];
+                            if (k >= thr && !isR) continue; // disallowed, or cannot enter a full list
+                            uint32_t cnt = 0;
+    #pragma unroll 4
+                            for (uint32_t j = 0; j < n_pad; j += 2) {
+                                const ulonglong2 v = kr[j >> 1];
+                                cnt += (v.x < k) + (v.y < k);
+                            }
+                            uint32_t rank = isR ? it + cnt : cnt;
+                            if (!isR) {
+                                uint32_t lo = 0, hi = rsize;
+                                while (lo < hi) {
+                                    uint32_t mid = (lo + hi) >> 1;
+                                    if (Rc[mid] < k) lo = mid + 1; else hi = mid;
+                                }
+                                rank += lo;
+                            }
+                            if (rank < kf) Rn[rank] = k;
+                        }
+                        rsize = min(rsize + n_in, kf);
+                        rcur ^= 1;
+                    }
+                }
+    #ifdef LEANN_STAMPS
+                const uint64_t stD = __builtin_amdgcn_s_memtime();
+    #endif
+                __syncthreads(); // B3
+    #ifdef LEANN_STAMPS
+                {
+                    const uint64_t stE = __builtin_amdgcn_s_memtime();
+                    stamp[0] += stB - st0; stamp[1] += stB1 - stB; stamp[2] += stC - stB1; stamp[3] += stB2 - stC;
+                    stamp[4] += stD - stB2; stamp[5] += stE - stD; stamp[6] += 1;
+                }
+    #endif
+                sel = *next_slot;
+                wsize = min(wsize + n_new, ef_l);
+                cur ^= 1;
+                hop++;
+            }
+        } else {
+            // Per hop, two workgroup barriers:
+            //   C  every wave: distances of the hop's unseen neighbours (rows in flight, wave-tree reductions)            | barrier
+            //   E  wave 0: the NEXT candidate, known before the merge — the merged beam's first unexpanded entry is the smaller of the old
+            //      beam's first unexpanded entry other than the one just expanded and the smallest new key; its index is the number of
+            //      keys below it — then that node's adjacency list (one id per lane, lists hold <= 64) through the visited table:
+            //      phase B of the next hop, into the other parity's buffers
+            //   D  waves 1 .. NW-1, meanwhile: merge by rank into the other beam buffer                                    | barrier
+            // The adjacency round trip of hop h + 1 thus runs under the merge of hop h.  Exactly one candidate is expanded per step, in
+            // the sequential order: same entry, same index as a scan of the merged list would give.
+            const uint32_t *const adj_base = lv == 0 ? adj0_p : adjU_p; // (as VALUES: an address-select between struct members puts the by-value GraphView in scratch)
+            uint32_t e_pref = LEANN_EMPTY;
+            auto phase_b = [&](uint32_t p, uint64_t ckey, uint32_t hidx) __attribute__((always_inline)) { // wave 0
+                uint64_t *skey = s.s_key + p * kstride;
+                uint32_t *snew = s.s_new + p * maxdeg;
+                const uint32_t node = key_id(ckey);
+                if (a.out_expanded && lv == (int)a.target_level && lane == 0 && hidx < a.exp_cap)
+                    a.out_expanded[(size_t)qi * a.exp_cap + hidx] = ((ckey >> 32) << 32) | node;
                 uint32_t n_new = 0;
-                bool ovf = (n_vis + deg > vis_limit);
+                const bool ovf = (n_vis + deg > vis_limit);
                 if (!ovf) {
-                    const uint32_t e = e_pref; // this node's list (a hop redone after a table migration reads the same register again)
+                    const uint32_t e = e_pref; // (a hop redone after a table migration reads the same register again)
                     bool isnew = false;
                     if (e != LEANN_EMPTY) isnew = hbm ? vis_insert_hbm(gtab, gbits, gen, e) : vis_insert_lds(table, hbits, e);
-                    unsigned long long m = __ballot(isnew);
-                    uint32_t pos = __popcll(m & ((1ull << lane) - 1ull));
-                    if (isnew) s.s_new[pos] = e;
+                    const unsigned long long m = __ballot(isnew);
+                    const uint32_t pos = __popcll(m & ((1ull << lane) - 1ull));
+                    if (isnew) snew[pos] = e;
                     n_new = __popcll(m);
                 }
                 n_vis += n_new;
                 n_evals += n_new;
                 if (!ovf) { if (lv == 0) hops0++; else hopsU++; }
-                if (lane < 8) s.s_key[n_new + lane] = ~0ull; // sentinels: the merge scans keys 8 at a time
-                if (filt_level && lane < 8) s_keyR[n_new + lane] = ~0ull;
+                if (lane < 8) skey[n_new + lane] = ~0ull; // sentinels: the merge scans keys 8 at a time
+                if (filt_level && lane < 8) (s_keyR + p * kstride)[n_new + lane] = ~0ull;
                 if (lane == 0) {
-                    s.misc[0] = n_new;
+                    s.misc[8 + p] = n_new;
                     if (ovf) s.misc[3] = 1;
                 }
+            };
+            if (wave == 0) {
+                e_pref = (uint32_t)lane < deg ? adj_list(adj_base, upoff_p, deg, lv, key_id(best))[lane] : LEANN_EMPTY;
+                phase_b(0u, best, 0u);
             }
-#ifdef LEANN_STAMPS
-            const uint64_t stB = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            uint32_t par = 0;
+            for (;;) {
+                uint64_t *Wc = W0 + cur * efp, *Wn = W0 + (cur ^ 1) * efp;
+#ifdef LEANN_STAMPS // diagnostic build only (scripts/stamps.sh): where does a hop spend its cycles?
+                const uint64_t st0 = __builtin_amdgcn_s_memtime();
 #endif
-            __syncthreads(); // B1
-#ifdef LEANN_STAMPS
-            const uint64_t stB1 = __builtin_amdgcn_s_memtime();
-#endif
-            const uint32_t table_full = s.misc[3];
-            if (table_full) {
-                // Table full: move the visited set one level up (LDS -> pool 1 -> pool 2) and redo this hop.
-                const uint32_t next = hbm + 1;
-                if (next > 2 || (next == 2 && !a.gpool2)) { aborted = true; break; } // defensive: see the pool comment above
-                __syncthreads(); // every thread has read the flag before it is cleared
-                if (tid == 0) {
-                    uint32_t *locks = next == 1 ? a.gpool_lock : a.gpool2_lock;
-                    const uint32_t ntab = next == 1 ? a.gpool_tables : a.gpool2_tables;
-                    uint32_t t = atomicAdd(&a.gpool_ctr[next == 1 ? 0 : 2], 1u), slot;
-                    for (uint32_t i = 0;; i++) { // holders never wait for anything, so a table always comes free
-                        slot = (t + i) % ntab;
-                        if (atomicCAS(&locks[slot], 0u, 1u) == 0u) break;
-                        if ((i % ntab) == ntab - 1) __builtin_amdgcn_s_sleep(32);
+                if (s.misc[3]) {
+                    // Table full: move the visited set one level up (LDS -> pool 1 -> pool 2), then wave 0 prepares this hop again.
+                    const uint32_t next = hbm + 1;
+                    if (next > 2 || (next == 2 && !a.gpool2)) { aborted = true; break; } // defensive: see the pool comment above
+                    __syncthreads(); // every thread has read the flag before it is cleared
+                    if (tid == 0) {
+                        uint32_t *locks = next == 1 ? a.gpool_lock : a.gpool2_lock;
+                        const uint32_t ntab = next == 1 ? a.gpool_tables : a.gpool2_tables;
+                        uint32_t t = atomicAdd(&a.gpool_ctr[next == 1 ? 0 : 2], 1u), slot;
+                        for (uint32_t i = 0;; i++) { // holders never wait for anything, so a table always comes free
+                            slot = (t + i) % ntab;
+                            if (atomicCAS(&locks[slot], 0u, 1u) == 0u) break;
+                            if ((i % ntab) == ntab - 1) __builtin_amdgcn_s_sleep(32);
+                        }
+                        s.misc[4] = slot;
+                        if (!hbm) s.misc[5] = atomicAdd(&a.gpool_ctr[1], 1u) + 1u; // pool 1 -> 2 keeps the generation
+                        s.misc[3] = 0;
                     }
-                    s.misc[4] = slot;
-                    if (!hbm) s.misc[5] = atomicAdd(&a.gpool_ctr[1], 1u) + 1u; // pool 1 -> 2 keeps the generation
-                    s.misc[3] = 0;
+                    __syncthreads();
+                    const uint32_t nslot = s.misc[4];
+                    const uint32_t nbits = next == 1 ? a.gpool_bits : a.gpool2_bits;
+                    unsigned long long *ntab_p = (next == 1 ? a.gpool : a.gpool2) + ((size_t)nslot << nbits);
+                    if (!hbm) {
+                        gen = s.misc[5];
+                        for (uint32_t i = tid; i < hsize; i += NW * 64) {
+                            uint32_t e = table[i];
+                            if (e != LEANN_EMPTY) vis_insert_hbm(ntab_p, nbits, gen, e);
+                        }
+                    } else {
+                        for (uint32_t i = tid; i < (1u << gbits); i += NW * 64) {
+                            const unsigned long long cur_e = __hip_atomic_load(&gtab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((uint32_t)(cur_e >> 32) == gen) vis_insert_hbm(ntab_p, nbits, gen, (uint32_t)cur_e);
+                        }
+                        __syncthreads(); // every probe of the old table has returned
+                        if (tid == 0) atomicExch(&a.gpool_lock[gslot], 0u);
+                    }
+                    gtab = ntab_p;
+                    gbits = nbits;
+                    gslot = nslot;
+                    hbm = next;
+                    vis_limit = (1u << gbits) - (1u << (gbits - 2));
+                    __syncthreads();
+                    if (wave == 0) phase_b(par, Wc[sel], hop);
+                    __syncthreads();
+                    continue;
                 }
-                __syncthreads();
-                const uint32_t nslot = s.misc[4];
-                const uint32_t nbits = next == 1 ? a.gpool_bits : a.gpool2_bits;
-                unsigned long long *ntab_p = (next == 1 ? a.gpool : a.gpool2) + ((size_t)nslot << nbits);
-                if (!hbm) {
-                    gen = s.misc[5];
-                    for (uint32_t i = tid; i < hsize; i += NW * 64) {
-                        uint32_t e = table[i];
-                        if (e != LEANN_EMPTY) vis_insert_hbm(ntab_p, nbits, gen, e);
+                const uint32_t n_new = s.misc[8 + par];
+                uint64_t *const skey = s.s_key + par * kstride;
+                const uint32_t *const snew = s.s_new + par * maxdeg;
+                uint64_t *const skeyR = s_keyR + par * kstride;
+                // ---- phase C: stream the new rows, R in flight per wave ------------------------------
+                for (uint32_t j0 = wave; j0 < n_new; j0 += NW * R) {
+                    uint32_t ids[R];
+                    float dd[R];
+                    int nrows = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        uint32_t j = j0 + r * NW;
+                        if (j < n_new) { ids[r] = snew[j]; nrows = r + 1; }
+                    }
+                    uint32_t abyte = 0, abit = 0;
+                    if (filt_level && lane < R && j0 + lane * NW < n_new) { // lane r fetches row r's allow bit alongside the rows
+                        const uint32_t e = snew[j0 + lane * NW];
+                        abyte = allow[e >> 3];
+                        abit = e & 7u;
+                    }
+                    if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd);
+                    else wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
+                    const unsigned long long amask = FILT ? __ballot((abyte >> abit) & 1u) : 0ull;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+                            if (r < nrows) {
+                                const uint64_t key = make_key(dd[r], ids[r]);
+                                skey[j0 + r * NW] = key;
+                                if (filt_level) skeyR[j0 + r * NW] = ((amask >> r) & 1ull) ? key : ~0ull;
+                            }
+                    }
+                }
+#ifdef LEANN_STAMPS
+                const uint64_t stC = __builtin_amdgcn_s_memtime();
+#endif
+                __syncthreads(); // B2
+#ifdef LEANN_STAMPS
+                const uint64_t stB2 = __builtin_amdgcn_s_memtime();
+#endif
+                uint32_t *next_slot = &s.misc[1 + (hop & 1)];
+                const uint32_t n_pad = (n_new + 7) & ~7u;
+                if (wave == 0) {
+                    // ---- phase E: next candidate; then phase B of the next hop ---------------------------------------------
+                    uint32_t u = LEANN_EMPTY;
+                    for (uint32_t base = 0; base < wsize && u == LEANN_EMPTY; base += 64) {
+                        const uint32_t i = base + lane;
+                        const unsigned long long m = __ballot(i < wsize && i != sel && !(Wc[i] & 1ull));
+                        if (m) u = base + (uint32_t)__ffsll((long long)m) - 1u;
+                    }
+                    const uint64_t c_old = u != LEANN_EMPTY ? Wc[u] : ~0ull;
+                    const uint64_t kj = (uint32_t)lane < n_new ? skey[lane] : ~0ull; // n_new <= 64: one key per lane
+                    const uint32_t hi = wave_min_u32((uint32_t)(kj >> 32));
+                    const uint32_t lo = wave_min_u32((uint32_t)(kj >> 32) == hi ? (uint32_t)kj : 0xFFFFFFFFu);
+                    const uint64_t c_new = n_new ? (((uint64_t)hi << 32) | lo) : ~0ull;
+                    uint32_t next = LEANN_EMPTY;
+                    uint64_t ckey = 0;
+                    if (c_old != ~0ull || c_new != ~0ull) {
+                        uint32_t rank;
+                        if ((c_old >> 1) < (c_new >> 1)) {
+                            rank = u + (uint32_t)__popcll(__ballot((kj >> 1) < (c_old >> 1)));
+                            ckey = c_old;
+                        } else {
+                            rank = 0;
+                            for (uint32_t base = 0; base < wsize; base += 64) {
+                                const uint32_t i = base + lane;
+                                rank += (uint32_t)__popcll(__ballot(i < wsize && (Wc[i] >> 1) < (c_new >> 1)));
+                            }
+                            ckey = c_new;
+                        }
+                        if (rank < ef_l) next = rank;
+                    }
+                    if (lane == 0) *next_slot = next;
+                    if (next != LEANN_EMPTY) {
+                        e_pref = (uint32_t)lane < deg ? adj_list(adj_base, upoff_p, deg, lv, key_id(ckey))[lane] : LEANN_EMPTY;
+                        phase_b(par ^ 1u, ckey, hop + 1); // waits for the list while the other waves merge
                     }
                 } else {
-                    for (uint32_t i = tid; i < (1u << gbits); i += NW * 64) {
-                        const unsigned long long cur = __hip_atomic_load(&gtab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((uint32_t)(cur >> 32) == gen) vis_insert_hbm(ntab_p, nbits, gen, (uint32_t)cur);
-                    }
-                    __syncthreads(); // every probe of the old table has returned
-                    if (tid == 0) atomicExch(&a.gpool_lock[gslot], 0u);
-                }
-                gtab = ntab_p;
-                gbits = nbits;
-                gslot = nslot;
-                hbm = next;
-                vis_limit = (1u << gbits) - (1u << (gbits - 2));
-                __syncthreads();
-                continue;
-            }
-            const uint32_t n_new = s.misc[0];
-            // ---- phase C: stream the new rows, R in flight per wave ------------------------------
-            for (uint32_t j0 = wave; j0 < n_new; j0 += NW * R) {
-                uint32_t ids[R];
-                float dd[R];
-                int nrows = 0;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    uint32_t j = j0 + r * NW;
-                    if (j < n_new) { ids[r] = s.s_new[j]; nrows = r + 1; }
-                }
-                uint32_t abyte = 0, abit = 0;
-                if (filt_level && lane < R && j0 + lane * NW < n_new) { // lane r fetches row r's allow bit alongside the rows
-                    const uint32_t e = s.s_new[j0 + lane * NW];
-                    abyte = allow[e >> 3];
-                    abit = e & 7u;
-                }
-                if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd);
-                else wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
-                const unsigned long long amask = FILT ? __ballot((abyte >> abit) & 1u) : 0ull;
-                if (lane == 0) {
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-                        if (r < nrows) {
-                            const uint64_t key = make_key(dd[r], ids[r]);
-                            s.s_key[j0 + r * NW] = key;
-                            if (filt_level) s_keyR[j0 + r * NW] = ((amask >> r) & 1ull) ? key : ~0ull;
-                        }
-                }
-            }
-#ifdef LEANN_STAMPS
-            const uint64_t stC = __builtin_amdgcn_s_memtime();
-#endif
-            __syncthreads(); // B2
-#ifdef LEANN_STAMPS
-            const uint64_t stB2 = __builtin_amdgcn_s_memtime();
-#endif
-            // ---- phase E (wave 0): the next candidate, known before the merge -------------------------------------
-            // The merged beam's first unexpanded entry is the smaller of (a) the first unexpanded entry of the OLD beam other than
-            // the one just expanded and (b) the smallest new key; its index in the merged beam is the number of keys below it.
-            // Same entry, same index as a scan of the merged list would give — but available one merge earlier, so wave 0 issues
-            // the next hop's adjacency load now and the other waves merge meanwhile.
-            uint32_t *next_slot = &s.misc[1 + (hop & 1)];
-            const uint32_t n_pad = (n_new + 7) & ~7u;
-            if (wave == 0) {
-                uint32_t u = LEANN_EMPTY;
-                for (uint32_t base = 0; base < wsize && u == LEANN_EMPTY; base += 64) {
-                    const uint32_t i = base + lane;
-                    const unsigned long long m = __ballot(i < wsize && i != sel && !(Wc[i] & 1ull));
-                    if (m) u = base + (uint32_t)__ffsll((long long)m) - 1u;
-                }
-                const uint64_t c_old = u != LEANN_EMPTY ? Wc[u] : ~0ull;
-                const uint64_t kj = (uint32_t)lane < n_new ? s.s_key[lane] : ~0ull; // n_new <= 64: one key per lane
-                const uint32_t hi = wave_min_u32((uint32_t)(kj >> 32));
-                const uint32_t lo = wave_min_u32((uint32_t)(kj >> 32) == hi ? (uint32_t)kj : 0xFFFFFFFFu);
-                const uint64_t c_new = n_new ? (((uint64_t)hi << 32) | lo) : ~0ull;
-                uint32_t next = LEANN_EMPTY, cnode = 0;
-                if (c_old != ~0ull || c_new != ~0ull) {
-                    uint32_t rank;
-                    if ((c_old >> 1) < (c_new >> 1)) {
-                        rank = u + (uint32_t)__popcll(__ballot((kj >> 1) < (c_old >> 1)));
-                        cnode = key_id(c_old);
-                    } else {
-                        rank = 0;
-                        for (uint32_t base = 0; base < wsize; base += 64) {
-                            const uint32_t i = base + lane;
-                            rank += (uint32_t)__popcll(__ballot(i < wsize && (Wc[i] >> 1) < (c_new >> 1)));
-                        }
-                        cnode = key_id(c_new);
-                    }
-                    if (rank < ef_l) next = rank;
-                }
-                if (lane == 0) *next_slot = next;
-                if (next != LEANN_EMPTY) // in flight across the merge and barrier B3
-                    e_pref = (uint32_t)lane < deg ? adj_list(adj_base, upoff_p, deg, lv, cnode)[lane] : LEANN_EMPTY;
-            } else {
-                // ---- phase D (waves 1 .. NW-1): merge by rank into the other buffer ---------------------------------
-                // One work item per old entry (rank = index + #new keys below it) and per new key (rank = #old below it, by
-                // binary search, + #new below it); the scan over the new keys reads 16 B per LDS instruction, 8 keys per
-                // unrolled step, so the loads pipeline instead of paying one LDS latency per key.
-                const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(s.s_key);
-                for (uint32_t it = tid - 64; it < wsize + n_new; it += (NW - 1) * 64) {
-                    const bool isW = it < wsize;
-                    uint64_t k = isW ? Wc[it] : s.s_key[it - wsize];
-                    if (isW && it == sel) k |= 1ull;
-                    const uint64_t kk = k >> 1;
-                    uint32_t cnt = 0;
-#pragma unroll 4
-                    for (uint32_t j = 0; j < n_pad; j += 2) {
-                        const ulonglong2 v = kp[j >> 1];
-                        cnt += ((v.x >> 1) < kk) + ((v.y >> 1) < kk);
-                    }
-                    uint32_t rank = isW ? it + cnt : cnt;
-                    if (!isW) {
-                        uint32_t lo = 0, hi = wsize;
-                        while (lo < hi) {
-                            uint32_t mid = (lo + hi) >> 1;
-                            if ((Wc[mid] >> 1) < kk) lo = mid + 1; else hi = mid;
-                        }
-                        rank += lo;
-                    }
-                    if (rank < ef_l) Wn[rank] = k;
-                }
-            }
-            if (filt_level) {
-                // R <- kf best of R ∪ {allowed new keys}: the same merge by rank, on the blanked copy of the new keys.
-                // Skipped (uniformly) when no allowed new key beats the current kf-th.
-                uint64_t *Rc = R0 + rcur * kfp, *Rn = R0 + (rcur ^ 1) * kfp;
-                const uint64_t thr = rsize == kf ? Rc[kf - 1] : ~0ull;
-                uint32_t n_in = 0;
-                for (uint32_t j = 0; j < n_new; j += 64) n_in += __popcll(__ballot(j + lane < n_new && s_keyR[j + lane] < thr));
-                if (n_in) {
-                    const ulonglong2 *kr = reinterpret_cast<const ulonglong2 *>(s_keyR);
-                    for (uint32_t it = tid; it < rsize + n_new; it += NW * 64) {
-                        const bool isR = it < rsize;
-                        const uint64_t k = isR ? Rc[it] : s_keyR[it - rsize];
-                        if (k >= thr && !isR) continue; // disallowed, or cannot enter a full list
+                    // ---- phase D (waves 1 .. NW-1): merge by rank into the other buffer ---------------------------------
+                    // One work item per old entry (rank = index + #new keys below it) and per new key (rank = #old below it, by
+                    // binary search, + #new below it); the scan over the new keys reads 16 B per LDS instruction, 8 keys per
+                    // unrolled step, so the loads pipeline instead of paying one LDS latency per key.
+                    const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(skey);
+                    for (uint32_t it = tid - 64; it < wsize + n_new; it += (NW - 1) * 64) {
+                        const bool isW = it < wsize;
+                        uint64_t k = isW ? Wc[it] : skey[it - wsize];
+                        if (isW && it == sel) k |= 1ull;
+                        const uint64_t kk = k >> 1;
                         uint32_t cnt = 0;
 #pragma unroll 4
                         for (uint32_t j = 0; j < n_pad; j += 2) {
-                            const ulonglong2 v = kr[j >> 1];
-                            cnt += (v.x < k) + (v.y < k);
+                            const ulonglong2 v = kp[j >> 1];
+                            cnt += ((v.x >> 1) < kk) + ((v.y >> 1) < kk);
                         }
-                        uint32_t rank = isR ? it + cnt : cnt;
-                        if (!isR) {
-                            uint32_t lo = 0, hi = rsize;
+                        uint32_t rank = isW ? it + cnt : cnt;
+                        if (!isW) {
+                            uint32_t lo = 0, hi = wsize;
                             while (lo < hi) {
                                 uint32_t mid = (lo + hi) >> 1;
-                                if (Rc[mid] < k) lo = mid + 1; else hi = mid;
+                                if ((Wc[mid] >> 1) < kk) lo = mid + 1; else hi = mid;
                             }
                             rank += lo;
                         }
-                        if (rank < kf) Rn[rank] = k;
+                        if (rank < ef_l) Wn[rank] = k;
                     }
-                    rsize = min(rsize + n_in, kf);
-                    rcur ^= 1;
                 }
-            }
+                if (filt_level) {
+                    // R <- kf best of R ∪ {allowed new keys}: the same merge by rank, on the blanked copy of the new keys.
+                    // Skipped (uniformly) when no allowed new key beats the current kf-th.
+                    uint64_t *Rc = R0 + rcur * kfp, *Rn = R0 + (rcur ^ 1) * kfp;
+                    const uint64_t thr = rsize == kf ? Rc[kf - 1] : ~0ull;
+                    uint32_t n_in = 0;
+                    for (uint32_t j = 0; j < n_new; j += 64) n_in += __popcll(__ballot(j + lane < n_new && skeyR[j + lane] < thr));
+                    if (n_in) {
+                        const ulonglong2 *kr = reinterpret_cast<const ulonglong2 *>(skeyR);
+                        for (uint32_t it = tid; it < rsize + n_new; it += NW * 64) {
+                            const bool isR = it < rsize;
+                            const uint64_t k = isR ? Rc[it] : skeyR[it - rsize];
+                            if (k >= thr && !isR) continue; // disallowed, or cannot enter a full list
+                            uint32_t cnt = 0;
+#pragma unroll 4
+                            for (uint32_t j = 0; j < n_pad; j += 2) {
+                                const ulonglong2 v = kr[j >> 1];
+                                cnt += (v.x < k) + (v.y < k);
+                            }
+                            uint32_t rank = isR ? it + cnt : cnt;
+                            if (!isR) {
+                                uint32_t lo = 0, hi = rsize;
+                                while (lo < hi) {
+                                    uint32_t mid = (lo + hi) >> 1;
+                                    if (Rc[mid] < k) lo = mid + 1; else hi = mid;
+                                }
+                                rank += lo;
+                            }
+                            if (rank < kf) Rn[rank] = k;
+                        }
+                        rsize = min(rsize + n_in, kf);
+                        rcur ^= 1;
+                    }
+                }
 #ifdef LEANN_STAMPS
-            const uint64_t stD = __builtin_amdgcn_s_memtime();
+                const uint64_t stD = __builtin_amdgcn_s_memtime();
 #endif
-            __syncthreads(); // B3
+                __syncthreads(); // B3: the merged beam and the next hop's unseen neighbours are in place
 #ifdef LEANN_STAMPS
-            {
-                const uint64_t stE = __builtin_amdgcn_s_memtime();
-                stamp[0] += stB - st0; stamp[1] += stB1 - stB; stamp[2] += stC - stB1; stamp[3] += stB2 - stC;
-                stamp[4] += stD - stB2; stamp[5] += stE - stD; stamp[6] += 1;
-            }
+                {
+                    const uint64_t stE = __builtin_amdgcn_s_memtime();
+                    stamp[0] += 0; stamp[1] += 0; stamp[2] += stC - st0; stamp[3] += stB2 - stC;
+                    stamp[4] += stD - stB2; stamp[5] += stE - stD; stamp[6] += 1;
+                }
 #endif
-            sel = *next_slot;
-            wsize = min(wsize + n_new, ef_l);
-            cur ^= 1;
-            hop++;
+                sel = *next_slot;
+                wsize = min(wsize + n_new, ef_l);
+                cur ^= 1;
+                hop++;
+                par ^= 1u;
+                if (sel == LEANN_EMPTY) break;
+            }
         }
         level_hops = hop;
         if (aborted) break;

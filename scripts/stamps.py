@@ -28,7 +28,8 @@ for nq in (16384, 64):
         s.search_batch_device(Q.ptr, nq, k, ef, ok.ptr, od.ptr, oc.ptr, None, None); la.sync()
     st = stamps.to_host().astype(np.float64)
     hops = st[:, 6].sum()
-    names = ["B adjacency+visited (wave0)", "wait B1", "C rows+dist", "wait B2", "D merge", "wait B3"]
+    # throughput form (batch 16384): B at the head of the hop; latency form (batch 64, 16 waves): B runs inside the E/D phase of the hop before
+    names = ["B adjacency+visited (wave0; latency form: 0)", "wait B1 (latency form: 0)", "C rows+dist", "wait B2", "E next candidate (+B) / D merge", "wait B3"]
     tot = st[:, :6].sum()
     print(f"nq={nq} ef={ef} feat={feat}: {hops/nq:.0f} hops/query, {tot/hops:.0f} cycles per hop (wave 0 view)")
     for i, nm in enumerate(names):
