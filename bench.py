@@ -61,6 +61,28 @@ SEED, GEN_R, GEN_CLUSTERS, GEN_SIGMA = 0x5EED0001, 64, 4096, 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """stdout carries exactly ONE JSON line (the driver's contract).  RCCL prints a version banner to the C-level stdout when a
+    communicator is made, so fd 1 is pointed at stderr for the whole run and the line goes out through the saved descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(out):
+    line = (json.dumps(out) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def host_cores():
     """threads this process may really use: affinity mask capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -231,7 +253,7 @@ def bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, lo
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -315,7 +337,7 @@ def bench_scan(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log):
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -346,6 +368,7 @@ def main():
                          "leann_backend_search_filtered_exact_batch_device) instead of walking the graph")
     args = ap.parse_args()
 
+    quiet_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -790,7 +813,7 @@ def main():
         except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
             out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -94,6 +94,47 @@ Files: `r02_hnsw10m_kernel_stats.csv` (every kernel of the process incl. index c
         md += f"* `{r['Name'][:60]}`: {r['Calls']} calls, {float(r['TotalDurationNs']) / 1e9:.2f} s ({r['Percentage']} %)\n"
     open(os.path.join(dst, "r02_headline_profile.md"), "w").write(md)
     print(md)
+    other_kernels()
+
+
+def other_kernels():
+    """profiles/r02_other_kernels.md: the kernels of the side workloads (scripts/profile_side.sh)"""
+    lines = ["# Round 2 — other kernels (1x MI355X; rocprofv3 --kernel-trace --stats of `bench.py --workload … --no-cpu-baseline --no-latency`)", ""]
+    for wl, pat in (("recompute10m_graph", "beam_search_feat_kernel"), ("recompute10m", "fused_fstat_kernel")):
+        pj, pc = os.path.join(src, f"prof_{wl}.json"), os.path.join(src, f"prof_{wl}", "r02_kernel_stats.csv")
+        if not (os.path.exists(pj) and os.path.exists(pc)):
+            continue
+        j = json.load(open(pj))
+        r = j["roofline"]
+        rows = [x for x in csv.DictReader(open(pc)) if pat in x["Name"]]
+        lines += [f"## {wl}: `{rows[0]['Name'][:70]}`" if rows else f"## {wl}", "",
+                  f"* bench line of the profiled run: {j['value']:.0f} queries/s, recall@10 {j.get('recall_at_10')}, {r['bound']} {r['achieved']:.1f} {r['unit']} = {r['frac'] * 100:.1f} % of peak"]
+        for x in rows:
+            lines.append(f"* kernel-stats row `{x['Name'][:60]}`: Calls {x['Calls']}, AverageNs {float(x['AverageNs']):.0f}, MinNs {x['MinNs']}, MaxNs {x['MaxNs']}")
+        if wl == "recompute10m_graph":
+            lines.append(f"* bench.py HIP-event average of the timed launches: {r['kernel_avg_ms']:.3f} ms; algorithmic bytes per query {r['algorithmic_bytes_per_query']:.0f} "
+                         f"({r['dist_evals_per_query']:.0f} evaluations x 520 B + {r['hops_per_query']:.0f} hops x 256 B); ceiling for random 520-B rows: 3.9-4.0 TB/s (`r02_gather_ceiling.txt`)")
+        lines.append("")
+    pm = os.path.join(src, "prof_mfma", "r02_counter_collection.csv")
+    if os.path.exists(pm):
+        busy, act = last_n(pm, "SQ_VALU_MFMA_BUSY_CYCLES", 1)[0], last_n(pm, "GRBM_GUI_ACTIVE", 1)[0]
+        lines += ["## fused_fstat_kernel matrix-pipe utilisation (separate `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass, the 9.5M-row launch of a step)", "",
+                  f"* SQ_VALU_MFMA_BUSY_CYCLES = {busy:.4e}, GRBM_GUI_ACTIVE = {act:.4e} summed over 8 XCDs -> MfmaUtil = busy / (active / 8 x 1024 SIMDs) = "
+                  f"**{busy / (act / 8 * 1024) * 100:.1f} %** of the resident cycles (round 1: 72.6 %)", ""]
+    pr = os.path.join(src, "prof_rdreq", "r02_counter_collection.csv")
+    if os.path.exists(pr):
+        a1, a2 = sum(last_n(pr, "TCC_EA0_RDREQ_sum", 4)) / 4, sum(last_n(pr, "TCC_EA0_RDREQ_DRAM_sum", 4)) / 4
+        lines += ["## hnsw10m: where the L2's read requests go (`--pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum`)", "",
+                  f"* {a1:.4e} requests per launch, {a2 / a1 * 100:.1f} % of them addressed to the DRAM path (x 128 B = {a1 * 128 / 1e9:.1f} GB = FETCH_SIZE x 2); the Infinity "
+                  "Cache sits behind that interface and no counter of it is exposed on this pool", ""]
+    fs = os.path.join(src, "forced_shard_rccl_world1.json")
+    if os.path.exists(fs):
+        open(os.path.join(dst, "r02_forced_shard_rccl_world1.json"), "w").write([l for l in open(fs) if l.startswith("{")][-1])
+        j = json.loads([l for l in open(fs) if l.startswith("{")][-1])
+        lines += ["## The N > 1 code path of bench.py with one rank (`LEANN_BENCH_FORCE_SHARD=1 python -m torch.distributed.run --nproc-per-node 1 … bench.py --workload hnsw100k`)", "",
+                  f"* shard mode through the library's RCCL group (ncclCommInitRank + ncclAllGather + merge kernel, tickets): {j['value']:.0f} queries/s, recall@10 {j['recall_at_10']:.4f}; "
+                  f"`{j['config'].get('value_unit_note', '')}`", ""]
+    open(os.path.join(dst, "r02_other_kernels.md"), "w").write("\n".join(lines))
 
 
 if __name__ == "__main__":
