@@ -814,6 +814,9 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
         emit(out)
+    if group is not None:
+        torch.cuda.synchronize()
+        group.close()  # ncclCommDestroy: collective-free, but every rank gets here
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -165,3 +165,35 @@ def test_fullsize_recompute_properties(la, po, gpu, monkeypatch):
     assert (lk == fk).all() and (ls.view(np.uint32) == fs.view(np.uint32)).all() and (lc == fc).all()
     assert allowed[lk.astype(np.int64)].all()
     L.leann_recompute_close(r)
+
+
+def test_fullsize_sharded_handle_properties(full):
+    """BASELINE configs[3]'s shape on one device: the 10M rows as two contiguous 5M shards behind ONE handle (csrc/shard.hip), searched
+    through the ordinary backend entry points — size-independent properties + recall + exact-score consistency."""
+    la, L, chk, X, Q, nq, s = full
+    half = (ROWS // 2) & ~63
+    sh = la.ShardedIndex.build_device(la.BackendType.Hnsw, [X.ptr, X.ptr + half * D * 4], [half, ROWS - half], D, D, M, EFC, [0, 0])
+    assert sh.len() == ROWS and sh.n_shards() == 2
+    h = sh.as_backend()
+    nqs = 2048
+    keys, dists, counts, _ = _search(la, h, Q.ptr, nqs, K, 96)
+    assert (counts == K).all() and (keys < ROWS).all() and (np.diff(dists, axis=1) >= 0).all()
+    assert all(len(set(r.tolist())) == K for r in keys[:512])
+    assert ((keys >= half).any(axis=1) & (keys < half).any(axis=1)).mean() > 0.5  # answers really come from both shards
+    k2, d2, _, _ = _search(la, h, Q.ptr, nqs, K, 96)                              # idempotent
+    assert (k2 == keys).all() and (d2 == dists).all()
+    ka, da, _, _ = _search(la, h, Q.ptr, 1000, K, 96)                             # batch split
+    kb, db, _, _ = _search(la, h, Q.ptr + 1000 * D * 4, nqs - 1000, K, 96)
+    assert (np.concatenate([ka, kb]) == keys).all() and (np.concatenate([da, db]) == dists).all()
+    ngt = 1000
+    gk, gs, gc = la.DeviceArray((ngt, K), np.uint64), la.DeviceArray((ngt, K), np.float32), la.DeviceArray(ngt, np.uint32)
+    chk(L.leann_scan_topk_device(X.ptr, ROWS, D, D, Q.ptr, ngt, K, None, 0, gk.ptr, gs.ptr, gc.ptr, None))
+    truth, tscore = gk.to_host(), gs.to_host()
+    rec = np.mean([len(set(keys[i].tolist()) & set(truth[i].tolist())) / K for i in range(ngt)])
+    assert rec >= 0.95, rec
+    for i in range(50):
+        common = {int(k): j for j, k in enumerate(truth[i])}
+        for j, kk in enumerate(keys[i]):
+            if int(kk) in common:
+                assert abs((1.0 - tscore[i][common[int(kk)]]) - dists[i][j]) <= 1e-5
+    h.close()
