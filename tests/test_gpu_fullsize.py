@@ -176,6 +176,12 @@ def test_fullsize_sharded_handle_properties(full):
     assert sh.len() == ROWS and sh.n_shards() == 2
     h = sh.as_backend()
     nqs = 2048
+
+    def _search(la, h, qptr, n_, k, ef):  # (per-query counters of a composite handle are [shards x nq x 4]: not asked for here)
+        dk, dd, dc = la.DeviceArray((n_, k), np.uint64), la.DeviceArray((n_, k), np.float32), la.DeviceArray(n_, np.uint32)
+        h.search_batch_device(qptr, n_, k, ef, dk.ptr, dd.ptr, dc.ptr, None, None)
+        la.sync()
+        return dk.to_host(), dd.to_host(), dc.to_host(), None
     keys, dists, counts, _ = _search(la, h, Q.ptr, nqs, K, 96)
     assert (counts == K).all() and (keys < ROWS).all() and (np.diff(dists, axis=1) >= 0).all()
     assert all(len(set(r.tolist())) == K for r in keys[:512])
