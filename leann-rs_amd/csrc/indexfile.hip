@@ -70,8 +70,11 @@ int leann_internal_save_to(const leann_backend *h, const std::string &path) {
         aU(std::max<size_t>(h->n_upper_lists * h->g.M, 1));
     int rc = leann_backend_graph_export(h, levels.data(), uo.data(), a0.data(), aU.data(), nullptr);
     if (rc) return rc;
-    FILE *f = fopen(path.c_str(), "wb");
-    if (!f) { leann_set_error("cannot create %s", path.c_str()); return LEANN_ERR_IO; }
+    // written beside the target and renamed over it: add_to_index rewrites the file it has just loaded, and a crash or a full disk
+    // half-way must not leave a truncated index behind (the loader would refuse it, but the old one would be gone)
+    const std::string tmp = path + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) { leann_set_error("cannot create %s", tmp.c_str()); return LEANN_ERR_IO; }
     FileHeader hd{};
     memcpy(hd.magic, "LEANNGX1", 8);
     hd.version = feat ? 2 : 1; hd.kind = (uint32_t)h->kind; hd.n = n; hd.d = (uint32_t)d; hd.M = h->g.M; hd.M0 = h->g.M0;
@@ -93,6 +96,7 @@ int leann_internal_save_to(const leann_backend *h, const std::string &path) {
         if (hipMemcpy2D(slab.data(), row_b, reinterpret_cast<const unsigned char *>(h->g.X) + r0 * dev_pitch, dev_pitch, row_b, rows,
                         hipMemcpyDeviceToHost) != hipSuccess) {
             fclose(f);
+            (void)remove(tmp.c_str());
             leann_set_error("leann_backend_save: device read failed: %s", hipGetErrorString(hipGetLastError()));
             return LEANN_ERR_DEVICE;
         }
@@ -102,13 +106,15 @@ int leann_internal_save_to(const leann_backend *h, const std::string &path) {
         std::vector<float> W((size_t)h->g.feat_h * d);
         if (hipMemcpy(W.data(), h->Wf32, W.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
             fclose(f);
+            (void)remove(tmp.c_str());
             leann_set_error("leann_backend_save: device read failed: %s", hipGetErrorString(hipGetLastError()));
             return LEANN_ERR_DEVICE;
         }
         ok = fwrite(W.data(), 4, W.size(), f) == W.size();
     }
     ok = (fclose(f) == 0) && ok;
-    if (!ok) { leann_set_error("short write to %s", path.c_str()); return LEANN_ERR_IO; }
+    if (!ok) { (void)remove(tmp.c_str()); leann_set_error("short write to %s", tmp.c_str()); return LEANN_ERR_IO; }
+    if (rename(tmp.c_str(), path.c_str()) != 0) { (void)remove(tmp.c_str()); leann_set_error("cannot move %s into place", tmp.c_str()); return LEANN_ERR_IO; }
     return LEANN_OK;
 }
 

@@ -136,3 +136,46 @@ def test_foreign_file_without_embeddings_keeps_the_reference_message(la, tmp_pat
     with pytest.raises(la.LeannError) as e:
         _open(la, tmp_path)
     assert e.value.code == 3 and "not a whole number" in str(e.value)
+
+
+def test_sharded_open_argument_and_file_errors_need_no_gpu(la, good, tmp_path):
+    """device lists are parsed, and the row source of a sharded open is located and checked, before any device is touched"""
+    stem = str(tmp_path / "documents.leann")
+    for spec in ("0,x", "3-1", "0,,1", "-2", "0-9999"):
+        with pytest.raises(la.LeannError) as e:
+            la.BackendSearcher.load(0, stem, 32, device=spec)
+        assert e.value.code == 1 and "device_spec" in str(e.value), spec
+    with pytest.raises(la.LeannError) as e:  # nothing to partition
+        la.BackendSearcher.load(0, stem, 32, device="0,1")
+    assert e.value.code == 2 and "documents.embeddings" in str(e.value)
+    (tmp_path / "documents.index").write_bytes(b"usearch" + bytes(200))  # a foreign file holds no rows we can read
+    with pytest.raises(la.LeannError) as e:
+        la.BackendSearcher.load(0, stem, 32, device="0,1")
+    assert e.value.code == 3 and "holds no rows to partition" in str(e.value)
+    (tmp_path / "documents.embeddings").write_bytes(b"\0" * (32 * 4 * 7 + 1))  # not a whole number of rows: ignored as a row source
+    with pytest.raises(la.LeannError) as e:
+        la.BackendSearcher.load(0, stem, 32, device="0,1")
+    assert e.value.code == 3
+    write_gx1(tmp_path / "documents.index", 0, **good)  # our own file is a row source; on a box without GPUs it stops at the device check
+    (tmp_path / "documents.embeddings").unlink()
+    if la.device_count() == 0:
+        with pytest.raises(la.LeannError) as e:
+            la.BackendSearcher.load(0, stem, 32, device="0,0")
+        assert e.value.code == 4 and "no CPU fallback" in str(e.value)
+    else:
+        s = la.BackendSearcher.load(0, stem, 32, device="0,0")
+        assert s.len() == 300
+        s.close()
+
+
+def test_sharded_entry_points_reject_bad_arguments(la):
+    import ctypes as C
+    L = la.lib()
+    h = C.c_void_p()
+    assert L.leann_sharded_from_handles(None, 0, 0, C.byref(h)) == 1
+    assert L.leann_sharded_open(None, 0, 32, b"0,1", C.byref(h)) == 1
+    assert L.leann_sharded_attach(None, None, 2, 0, 0, C.byref(h)) == 1
+    assert L.leann_sharded_search_batch_device(None, None, 1, 1, 1, None, None, None, None, None) == 1
+    assert L.leann_sharded_wait(None, 0, None) == 1
+    assert L.leann_sharded_len(None) == 0 and L.leann_sharded_shards(None) == 0
+    L.leann_sharded_close(None)
