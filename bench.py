@@ -480,8 +480,21 @@ def main():
         # one RCCL communicator of the LIBRARY's own: local traversal, ncclAllGather of the packed per-shard block, merge kernel
         # (csrc/shard.hip).  torch.distributed only carries the 128-byte id from rank 0 to the other ranks.
         from leann_rs_amd.shard import rccl_group
-        group = rccl_group(searcher, corpus_total, world, rank)
-        log(f"rank {rank}: attached to the library's RCCL group ({group.n_shards()} shards, {group.len()} rows)")
+        ok = 1
+        try:
+            group = rccl_group(searcher, corpus_total, world, rank)
+        except Exception as e:  # noqa: BLE001  (e.g. librccl.so not resolvable): every rank agrees on the fallback below
+            ok, group = 0, None
+            print(f"[bench] rank {rank}: library RCCL group unavailable: {e}", file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if group is not None:
+                group.close()
+            group, rccl = None, False
+            log("falling back to the torch.distributed all-gather + HIP merge kernel for the exchange step")
+        else:
+            log(f"rank {rank}: attached to the library's RCCL group ({group.n_shards()} shards, {group.len()} rows)")
     ev_search = [torch.cuda.Event() for _ in range(2)]
     ev_xdone = [None, None]
 
