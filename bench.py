@@ -675,7 +675,8 @@ def main():
                         + f"batch {B} queries/step, clustered synthetic (r={GEN_R}, C={GEN_CLUSTERS}, sigma={GEN_SIGMA})",
             "rows_per_gpu": rows, "corpus_rows_total": corpus_total, "dims": d, "M": M, "ef_construction": efc,
             "ef_search": ef, "top_k": k, "batch": B,
-            "parallelism": ("single" if world == 1 else (f"shard{world}+rccl_allgather" if shard else f"replica{world}")),
+            "parallelism": ((f"shard{world}+rccl_allgather" if rccl else f"shard{world}+{dist.get_backend()}_allgather(torch; rehearsal)") if shard
+                            else ("single" if world == 1 else f"replica{world}")),
             "index_build_s": build_s,
             **({"filter_selectivity": args.filter_selectivity,
                 "filter_note": "side experiment: allow-bitmap evaluated inside the traversal; recall vs the exact filtered top-k"}
