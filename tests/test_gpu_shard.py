@@ -159,3 +159,39 @@ def test_open_with_a_device_list_shards_a_stock_directory(la, po, gpu, tmp_path)
     k3, _, _ = s.search_batch(Q, 10, 64)
     assert recall_at_k(k3, po.exact_topk(X[:5000], Q, 10)) >= 0.95
     s.close()
+
+
+def test_sharded_handle_is_reentrant(la, po, gpu):
+    """BackendSearcher is Send + Sync (traits.rs:11): 12 threads search ONE composite handle at once — batches of different sizes and
+    single queries, two result slots rotating under them — and every answer equals the single-threaded one."""
+    import threading
+    n, d, G, k, ef, M = 6000, 64, 4, 10, 40, 8
+    X = synth(po, n, d)
+    Q = synth(po, 12 * 30, d, stream=1)
+    lows = [((n * g) // G) & ~63 for g in range(G)] + [n]
+    parts = [la.DeviceArray.from_host(X[lows[g]:lows[g + 1]]) for g in range(G)]
+    sh = la.ShardedIndex.build_device(la.BackendType.Hnsw, [p.ptr for p in parts], [lows[g + 1] - lows[g] for g in range(G)], d, d, M, 32, [0] * G,
+                                      keep=parts)
+    s = sh.as_backend()
+    ref_k, ref_d, _ = s.search_batch(Q, k, ef)
+    bad = []
+
+    def work(t):
+        rows = range(t * 30, (t + 1) * 30)
+        for rep in range(3):
+            if t % 2:
+                kk, dd, _ = s.search_batch(Q[rows.start:rows.stop], k, ef)
+                if not ((kk == ref_k[rows.start:rows.stop]).all() and (dd == ref_d[rows.start:rows.stop]).all()):
+                    bad.append((t, rep))
+            else:
+                for i in rows:
+                    k1, d1 = s.search(Q[i], k, ef)
+                    if not ((k1 == ref_k[i]).all() and (d1 == ref_d[i]).all()):
+                        bad.append((t, rep, i))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(12)]
+    [t.start() for t in th]
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    assert not bad, bad[:5]
+    s.close()
