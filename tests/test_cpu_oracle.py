@@ -289,3 +289,16 @@ def test_regression_pins_oracle(po):
     Gr = po.Graph.build_hnsw(X, M=8, efc=32)
     k, dd, c, st = Gr.search_batch(Q, 5, 24, 0, 1)
     assert (k == z["hnsw_keys"]).all() and (dd.view(np.uint32) == z["hnsw_dists"]).all() and (st == z["hnsw_stats"]).all()
+
+
+def test_regression_pins_v2_oracle(po):
+    """tests/golden/pins_v2.npz (round 2): Vamana search, filtered search, recompute provider, cross-shard merge — the oracle must
+    keep reproducing the bits it produced when the HIP path was validated against it (tests/golden/make_pins_v2.py regenerates)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_pins_v2", os.path.join(GOLD, "make_pins_v2.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    now, z = m.build(), np.load(os.path.join(GOLD, "pins_v2.npz"))
+    assert set(now) == set(z.files)
+    for k in z.files:
+        assert np.array_equal(now[k], z[k]), k

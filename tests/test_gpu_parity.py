@@ -329,3 +329,52 @@ def test_regression_pins_gpu(la, po, gpu):
     st = s.stats()
     assert st["n_dist_evals"] == int(z["hnsw_stats"][:, 0].sum()) and st["n_hops_base"] == int(z["hnsw_stats"][:, 1].sum())
     s.close()
+
+
+def test_regression_pins_v2_gpu(la, po, gpu):
+    """The HIP path reproduces tests/golden/pins_v2.npz: Vamana GreedySearch and the filtered search bit for bit (ids, f32 distance bits,
+    counters), the synthetic recompute inputs bit for bit, embeddings within 1e-6, the cross-shard merge bit for bit."""
+    import ctypes as C
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pins_v2.npz"))
+    X = po.gen_rows(SEED, 96, 32, 64, 1.0, 0, 0, 2000)
+    Q = po.gen_rows(SEED, 96, 32, 64, 1.0, 1, 0, 16)
+    V = po.Graph.build_vamana(X, R=12, L=32, alpha=1.2)
+    lv, uo, a0, aU = V.export()
+    assert int(a0.astype(np.uint64).sum()) == int(z["vam_graph"][0]) and V.entry == int(z["vam_graph"][1])
+    s = la.BackendSearcher.from_arrays(la.BackendType.DiskAnn, X, 12, 12, 0, V.entry, lv, uo, a0, aU)
+    for L_ in (8, 40):
+        s.stats(reset=True)
+        k, dd, c = s.search_batch(Q, 6, L_)
+        st = s.stats()
+        assert (k == z[f"vam_keys_L{L_}"]).all() and (dd.view(np.uint32) == z[f"vam_dists_L{L_}"]).all()
+        assert st["n_dist_evals"] == int(z[f"vam_stats_L{L_}"][:, 0].sum()) and st["n_hops_base"] == int(z[f"vam_stats_L{L_}"][:, 1].sum())
+    s.close()
+    G = po.Graph.build_hnsw(X, M=8, efc=32)
+    lv, uo, a0, aU = G.export()
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, 8, 16, G.max_level, G.entry, lv, uo, a0, aU)
+    allow = np.packbits((np.arange(2000) % 3) == 0, bitorder="little")
+    k, dd, c = s.search_filtered_batch(Q, 5, 24, allow)
+    assert (k == z["filt_keys"]).all() and (dd.view(np.uint32) == z["filt_dists"]).all() and (c == z["filt_counts"]).all()
+    s.close()
+    L, chk = la.lib(), la._native.check
+    gF, gW = la.DeviceArray((40, 64), np.uint16), la.DeviceArray((64, 96), np.uint16)
+    chk(L.leann_synth_features_device(SEED, 64, 0, 16, 1.0, 0, 5, 40, gF.ptr, None))
+    chk(L.leann_synth_weights_device(SEED, 64, 96, gW.ptr, None))
+    la.sync()
+    assert (gF.to_host()[:4] == z["rc_features"]).all() and int(gW.to_host().astype(np.uint64).sum()) == int(z["rc_weights_crc"][0])
+    r = C.c_void_p()
+    chk(L.leann_recompute_create(gF.ptr, 40, 64, gW.ptr, 96, 0, 0, C.byref(r)))
+    dE = la.DeviceArray((40, 96), np.float32)
+    chk(L.leann_recompute_encode_device(r, 0, 40, dE.ptr, None))
+    la.sync()
+    assert np.abs(dE.to_host()[:8] - z["rc_embed"].view(np.float32)).max() <= 1e-6
+    L.leann_recompute_close(r)
+    mk = np.array([[[5, 9, 40]], [[7, 8, 41]], [[1, 2, 3]]], np.uint64)
+    md = np.array([[[0.1, 0.3, 0.5]], [[0.1, 0.2, 0.9]], [[0.4, 0.45, 0.0]]], np.float32)
+    mc = np.array([[3], [3], [2]], np.uint32)
+    dk, dd_, dc = la.DeviceArray.from_host(mk), la.DeviceArray.from_host(md), la.DeviceArray.from_host(mc)
+    ok_, od_, oc_ = la.DeviceArray((1, 5), np.uint64), la.DeviceArray((1, 5), np.float32), la.DeviceArray(1, np.uint32)
+    chk(L.leann_merge_topk_device(dk.ptr, dd_.ptr, dc.ptr, 3, 1, 3, 5, 0, ok_.ptr, od_.ptr, oc_.ptr, None))
+    la.sync()
+    assert (ok_.to_host()[0] == z["merge_keys"]).all() and (od_.to_host()[0].view(np.uint32) == z["merge_dists"]).all()
