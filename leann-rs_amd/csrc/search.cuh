@@ -649,8 +649,21 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                         abyte = allow[e >> 3];
                         abit = e & 7u;
                     }
+#ifndef LEANN_NO_ADJ_TOUCH
+                    // Latency form only: touch the adjacency lists of the rows being evaluated (two 128-B lines each, one lane per
+                    // line).  The next candidates come from these rows, so when phase E picks one its list is an L2 hit instead of
+                    // an HBM round trip at the head of the dependent chain; the chip is idle in this mode, the +8 % traffic is free.
+                    // (An ordinary load issued BEFORE the row loads and consumed behind them: the rows' wait covers it, and the
+                    // compiler keeps its register reserved until then.)
+                    uint32_t touch = 0;
+                    if (lv == 0 && (uint32_t)(lane >> 1) < (uint32_t)nrows && (uint32_t)(lane & 1) * 32u < deg)
+                        touch = adj0_p[(size_t)snew[j0 + (uint32_t)(lane >> 1) * NW] * deg + (uint32_t)(lane & 1) * 32u];
+#endif
                     if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd);
                     else wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
+#ifndef LEANN_NO_ADJ_TOUCH
+                    asm volatile("" ::"v"(touch));
+#endif
                     const unsigned long long amask = FILT ? __ballot((abyte >> abit) & 1u) : 0ull;
                     if (lane == 0) {
 #pragma unroll
