@@ -302,3 +302,26 @@ def test_regression_pins_v2_oracle(po):
     assert set(now) == set(z.files)
     for k in z.files:
         assert np.array_equal(now[k], z[k]), k
+
+
+def test_traced_three_level_graph_with_ties(po):
+    """tests/golden/traced_graph_400.json: 400 nodes on three levels, exact integer arithmetic, 20 duplicated vectors (ties broken by
+    id), 52 HNSW cases (k > ef included) and 39 GreedySearch cases traced by the independent pure-Python implementation
+    (tests/golden/make_traced_graph_v2.py) — ids, distances, expansion counts and evaluation counts, both oracle formulations."""
+    from util import traced_graph
+    fx, X, levels, upper_off, adj0, adjU = traced_graph("traced_graph_400.json")
+    G = po.Graph.from_arrays(X, fx["M"], fx["M0"], fx["max_level"], fx["entry"], levels, upper_off, adj0, adjU)
+    for c in fx["cases"]:
+        q = np.array(c["query"], np.float32)
+        for algo in (0, 1):
+            keys, dists, st = G.search(q, c["k"], max(c["ef"], c["k"]), algo)
+            assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]], (c["k"], c["ef"], algo)
+            assert int(st[0]) == c["n_evals"] and int(st[1]) == len(c["expanded_base"]) and int(st[2]) == c["hops_upper"]
+    V = po.Graph.from_arrays(X, fx["M0"], fx["M0"], 0, fx["entry"], np.zeros(fx["n"], np.uint8), np.zeros(fx["n"], np.uint32), adj0,
+                             np.zeros((0, fx["M0"]), np.uint32))
+    for c in fx["vamana_cases"]:
+        q = np.array(c["query"], np.float32)
+        for algo in (0, 1):
+            keys, dists, st = V.search(q, c["k"], c["L"], algo)
+            assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]]
+            assert int(st[0]) == c["n_evals"] and int(st[1]) == len(c["expanded"])

@@ -378,3 +378,34 @@ def test_regression_pins_v2_gpu(la, po, gpu):
     chk(L.leann_merge_topk_device(dk.ptr, dd_.ptr, dc.ptr, 3, 1, 3, 5, 0, ok_.ptr, od_.ptr, oc_.ptr, None))
     la.sync()
     assert (ok_.to_host()[0] == z["merge_keys"]).all() and (od_.to_host()[0].view(np.uint32) == z["merge_dists"]).all()
+
+
+def test_traced_three_level_graph_with_ties_gpu(la, gpu):
+    """tests/golden/traced_graph_400.json through the HIP kernel (no oracle involved): ids, distances and the visit counters of the
+    independent pure-Python trace — three levels, duplicated vectors (ties -> lower id), k > ef, single queries (16-wave latency form)
+    and one batch (same form below 512 queries), HNSW and GreedySearch."""
+    from util import traced_graph
+    fx, X, levels, upper_off, adj0, adjU = traced_graph("traced_graph_400.json")
+    s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, fx["M"], fx["M0"], fx["max_level"], fx["entry"], levels, upper_off, adj0, adjU)
+    for c in fx["cases"]:
+        q = np.array(c["query"], np.float32)
+        s.stats(reset=True)
+        keys, dists = s.search(q, c["k"], c["ef"])
+        st = s.stats()
+        assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]], (c["k"], c["ef"])
+        assert st["n_dist_evals"] == c["n_evals"] and st["n_hops_base"] == len(c["expanded_base"]) and st["n_hops_upper"] == c["hops_upper"]
+    # the throughput form of the hop loop (4 waves per query): replicate one case 600 times so that the batch exceeds 512 queries
+    c = fx["cases"][0]
+    Q = np.tile(np.array(c["query"], np.float32), (600, 1))
+    k, dd, cnt = s.search_batch(Q, c["k"], c["ef"])
+    assert (k == np.array(c["ids"], np.uint64)).all() and (dd == np.array(c["dists"], np.float32)).all()
+    s.close()
+    v = la.BackendSearcher.from_arrays(la.BackendType.DiskAnn, X, fx["M0"], fx["M0"], 0, fx["entry"], np.zeros(fx["n"], np.uint8),
+                                       np.zeros(fx["n"], np.uint32), adj0, np.zeros((0, fx["M0"]), np.uint32))
+    for c in fx["vamana_cases"]:
+        v.stats(reset=True)
+        keys, dists = v.search(np.array(c["query"], np.float32), c["k"], c["L"])
+        st = v.stats()
+        assert keys.tolist() == c["ids"] and dists.tolist() == [float(x) for x in c["dists"]]
+        assert st["n_dist_evals"] == c["n_evals"] and st["n_hops_base"] == len(c["expanded"])
+    v.close()

@@ -17,10 +17,11 @@ def recall_at_k(found, truth):
     return hits / (len(truth) * k)
 
 
-def traced_graph():
-    """tests/golden/traced_graph_64.json as arrays: the hand-built 64-node graph + the independently traced expectations"""
+def traced_graph(name="traced_graph_64.json"):
+    """tests/golden/traced_graph_64.json (hand-built 64-node graph) or traced_graph_400.json (400 nodes, three levels, duplicated
+    vectors) as arrays + the independently traced expectations"""
     import json, os
-    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traced_graph_64.json")))
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
     X = np.array(fx["vectors"], np.float32)
     levels = np.array(fx["levels"], np.uint8)
     upper_off = np.concatenate([[0], np.cumsum(levels)[:-1]]).astype(np.uint32)
