@@ -149,6 +149,9 @@ extern "C" int leann_debug_fstat_stamps(unsigned long long *out16, int reset) {
 #ifndef LEANN_FSTAT_PFD
 #define LEANN_FSTAT_PFD 0 // k-steps between a feature fragment's last MFMA and its refill for the next unit (experiment knob)
 #endif
+#ifndef LEANN_FSTAT_DB
+#define LEANN_FSTAT_DB 0 // experiment: a SECOND set of feature registers, refilled for the next unit inside the first weight visit
+#endif
 // Fragment-major copy of the features for fused_fstat_kernel: Ft[block of 32 rows][k-step][lane = lh * 32 + row][8 bf16], i.e.
 // the 1 KiB a wave loads per (block, k-step) is contiguous (8 full lines per instruction instead of 32 quarter lines of a
 // row-major read: the row-major form costs ~170 issue cycles per load next to the MFMAs).  Rows are padded to whole units.
@@ -248,14 +251,23 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
         }
     };
 
+    auto load_feature1 = [&](bf16x8 (&a)[RB][KS], uint64_t prow0, int rb, int ks) __attribute__((always_inline)) {
+        if constexpr (TILED) a[rb][ks] = reinterpret_cast<const bf16x8 *>(F)[((prow0 / 32 + rb) * KS + ks) * 64 + lane];
+        else if constexpr (LIST) a[rb][ks] = *reinterpret_cast<const bf16x8 *>(F + (uint64_t)lrow[rb] * H + ks * 16 + lh * 8);
+        else {
+            const uint64_t row = prow0 + rb * 32 + l31;
+            a[rb][ks] = *reinterpret_cast<const bf16x8 *>(F + (row < n ? row : n - 1) * H + ks * 16 + lh * 8);
+        }
+    };
     if (blockIdx.x >= n_units) return;
     if (em.thr) sThr[tid] = em.thr[tid]; // 256 threads, FSTAT_MAX_QUERIES = 256 slots; // visible to every wave long before its first use (a barrier per sub-slice)
-    bf16x8 a[RB][KS];
+    constexpr bool DB = LEANN_FSTAT_DB && !LIST;
+    bf16x8 aA[RB][KS], aB[DB ? RB : 1][DB ? KS : 1];
     {
         const uint64_t prow0 = (uint64_t)blockIdx.x * UNIT + (uint64_t)wave * (RB * 32);
         set_lrow(prow0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) load_features(a, prow0, ks);
+        for (int ks = 0; ks < KS; ks++) load_features(aA, prow0, ks);
     }
     uint32_t step = 0; // sub-slices consumed so far: buffer = step & 1
     stage(0, 0);
@@ -265,11 +277,12 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
     f32x16 zero16;
 #pragma unroll
     for (int i = 0; i < 16; i++) zero16[i] = 0.f;
-    for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    auto unit_body = [&](auto &a, auto &an, const uint64_t unit) __attribute__((always_inline)) {
         const uint64_t prow0 = unit * UNIT + (uint64_t)wave * (RB * 32);
         const uint64_t next_unit = unit + gridDim.x;
         const bool last_unit = next_unit >= n_units;
-        set_lrow((last_unit ? unit : next_unit) * UNIT + (uint64_t)wave * (RB * 32)); // long before the last G visit reads them
+        const uint64_t nprow0 = (last_unit ? unit : next_unit) * UNIT + (uint64_t)wave * (RB * 32);
+        set_lrow(nprow0); // long before the last G visit reads them
         float ssq[RB][16];
         f32x16 accA[RB], accB[RB]; // ping-pong accumulators of the column tiles; the finished one is squared into ssq
 #pragma unroll
@@ -329,7 +342,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
 #ifdef LEANN_STAMPS
             const uint64_t tB = __builtin_amdgcn_s_memtime();
 #endif
-            if constexpr (KIND == 0) {
+            if constexpr (KIND == 0 || KIND == 3) {
                 // 4 column tiles x KS k-steps, flat: fragment f+RING is requested while fragment f is multiplied.  The reads
                 // are asm statements (the compiler's scheduler otherwise sinks every read to just before its use, which with
                 // one wave per SIMD exposes the LDS latency 64 times per sub-slice); their lgkmcnt is counted by hand.
@@ -339,7 +352,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                     constexpr int f = decltype(fc)::value;
                     FSTAT_DS_READ(bq[f], waddr, (f % KS) * KSB + (f / KS) * 1024);
                 });
-                static_for<4 * KS>([&accA, &accB, &bq, &a, &ssq, &waddr, &dsb, &dld, &goff](auto fc) __attribute__((always_inline)) {
+                static_for<4 * KS>([&accA, &accB, &bq, &a, &an, &ssq, &waddr, &dsb, &dld, &goff, &nprow0, &load_feature1, &j](auto fc) __attribute__((always_inline)) {
                     constexpr int f = decltype(fc)::value, ct = f / KS, ks = f % KS, NF = 4 * KS;
                     f32x16 &c0 = (ct & 1) ? accB[0] : accA[0];
                     f32x16 &c1 = (ct & 1) ? accB[1] : accA[1];
@@ -375,6 +388,8 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                             FSTAT_W_NR_SQ3(c0, c1, a[0][ks], a[1][ks], b, NF - f - 1, ssq[0][13], p0[13], ssq[1][13], p1[13], ssq[0][14], p0[14],
                                            ssq[1][14], p1[14], ssq[0][15], p0[15], ssq[1][15], p1[15]);
                     }
+                    if constexpr (DB && KIND == 3 && f < RB * KS) // next unit's fragments: all issued in the first half of the visit,
+                        load_feature1(an, nprow0, f / KS, f % KS); // so that the vmcnt(0) opening the next visit finds them landed
                 });
                 // the last MFMAs' results: hipcc does not see the MFMA -> VALU hazard (no hardware interlock); the operands pin every
                 // compiler-generated reader or copy of the accumulators (loop-carried across visits) below the pad
@@ -407,11 +422,10 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                 const int qt = j - nsw;
                 // last sub-slice of the unit (the last query tile): each feature register is refilled for the next unit right after its last
                 // use; unconditional (the last unit re-reads its own rows) so that no branch or register copy sits between MFMAs
-                const uint64_t nprow0 = (last_unit ? unit : next_unit) * UNIT + (uint64_t)wave * (RB * 32);
                 f32x16 sc[RB];
                 // (the ring's first reads sit inside each instantiation: with a branch between an asm read and the statement that
                 // waits for it, hipcc copies the not-yet-landed destination registers at the join)
-                auto g_loop = [&sc, &a, &waddr, &nprow0, &load_features, &dsb, &dld, &goff](auto pfc) __attribute__((always_inline)) {
+                auto g_loop = [&sc, &a, &an, &waddr, &nprow0, &load_features, &dsb, &dld, &goff](auto pfc) __attribute__((always_inline)) {
                     constexpr bool PF = decltype(pfc)::value;
                     bf16x8 gq[RING + 1];
                     static_for<RING>([&gq, &waddr](auto fc) __attribute__((always_inline)) {
@@ -420,7 +434,7 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                     });
                     // k-step major (pieces hi, lo, lo2 innermost): a feature fragment is dead after its k-step, so the next unit's
                     // feature loads spread over the whole visit instead of bunching in the last third
-                    static_for<KS>([&sc, &gq, &a, &waddr, &nprow0, &load_features, &dsb, &dld, &goff](auto kc) __attribute__((always_inline)) {
+                    static_for<KS>([&sc, &gq, &a, &an, &waddr, &nprow0, &load_features, &dsb, &dld, &goff](auto kc) __attribute__((always_inline)) {
                         constexpr int ks = decltype(kc)::value, f = 3 * ks, NF = 3 * KS;
                         bf16x8 &s0 = gq[f % 5], &s1 = gq[(f + 1) % 5], &s2 = gq[(f + 2) % 5], &s4 = gq[(f + 4) % 5];
                         constexpr int o4 = ((f + 4) / 3) * KSB + ((f + 4) % 3) * 1024, o5 = ((f + 5) / 3) * KSB + ((f + 5) % 3) * 1024,
@@ -437,14 +451,14 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
                             FSTAT_GK_T0(sc[0], sc[1], s0, s1, s2, a[0][ks], a[1][ks], waddr, goff, dsb[dt], dld[dt], doff);
                         }
                         // refill for the next unit, LEANN_FSTAT_PFD k-steps behind the fragment's last MFMA
-                        if constexpr (PF && ks >= LEANN_FSTAT_PFD) load_features(a, nprow0, ks - LEANN_FSTAT_PFD);
+                        if constexpr (PF && ks >= LEANN_FSTAT_PFD) load_features(an, nprow0, ks - LEANN_FSTAT_PFD);
                     });
                     if constexpr (PF)
-                        static_for<LEANN_FSTAT_PFD>([&a, &nprow0, &load_features](auto kc) __attribute__((always_inline)) {
-                            load_features(a, nprow0, KS - LEANN_FSTAT_PFD + decltype(kc)::value);
+                        static_for<LEANN_FSTAT_PFD>([&an, &nprow0, &load_features](auto kc) __attribute__((always_inline)) {
+                            load_features(an, nprow0, KS - LEANN_FSTAT_PFD + decltype(kc)::value);
                         });
                 };
-                g_loop(std::integral_constant<bool, KIND == 2>{});
+                g_loop(std::integral_constant<bool, KIND == 2 && !DB>{});
                 asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1])); // as above: no reader of the score tiles above the pad
 #ifdef LEANN_STAMPS
                 if (qt == 0) stGL += __builtin_amdgcn_s_memtime() - tB; else stGL1 += __builtin_amdgcn_s_memtime() - tB;
@@ -514,9 +528,22 @@ __global__ void __launch_bounds__(256) fused_fstat_kernel(const uint16_t *__rest
 #endif
             step++;
         };
-        for (int j = 0; j < nsw; j++) visit(j, std::integral_constant<int, 0>{});
+        if constexpr (DB) { // the first weight visit also refills the OTHER register set for the next unit
+            visit(0, std::integral_constant<int, 3>{});
+            for (int j = 1; j < nsw; j++) visit(j, std::integral_constant<int, 0>{});
+        } else {
+            for (int j = 0; j < nsw; j++) visit(j, std::integral_constant<int, 0>{});
+        }
         for (int j = nsw; j < nsub - 1; j++) visit(j, std::integral_constant<int, 1>{});
         visit(nsub - 1, std::integral_constant<int, 2>{});
+    };
+    if constexpr (DB) {
+        for (uint64_t unit = blockIdx.x; unit < n_units; unit += 2 * (uint64_t)gridDim.x) {
+            unit_body(aA, aB, unit);
+            if (unit + gridDim.x < n_units) unit_body(aB, aA, unit + gridDim.x);
+        }
+    } else {
+        for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) unit_body(aA, aA, unit);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pieces staged during the last visit: no DMA into LDS after the workgroup ends
 #ifdef LEANN_STAMPS
