@@ -685,8 +685,10 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
-            "boundary_note": "achieved = algorithmic bytes / kernel time; the bytes cross the L2<->fabric boundary, part of them served by the "
-                             "256 MB Infinity Cache rather than HBM (upper levels + hot lists; profiles/r02_hbm_mall_split.md)",
+            "boundary_note": "achieved = algorithmic bytes / kernel time; the bytes cross the L2<->fabric boundary (all of the L2's read "
+                             "requests take the DRAM path, TCC_EA0_RDREQ_DRAM = 100 %); the memory-side 256 MB Infinity Cache sits behind "
+                             "that interface with no counter exposed on this pool, so the HBM / Infinity-Cache split is unmeasured "
+                             "(profiles/r02_other_kernels.md)",
             "kernel": ("beam_search_filtered_kernel" if allow is not None else
                        "beam_search_feat_kernel<1,8,4> (+ score_mfma_kernel query projection)" if rgraph else
                        "beam_search_kernel<3,4,4,false>" if ld == 768 else "beam_search_kernel"),

@@ -257,6 +257,14 @@ template <int T, int R>
 static int launch_search_feat(const GraphView &g, const SearchArgs &a, hipStream_t st) {
     size_t lds;
     if (int rc = search_lds_checked(g, a, &lds, a.nq <= 512 ? 16 : 4)) return rc;
+    if (T == 1 && g.feat_h == 256 && !getenv("LEANN_DEBUG_NO_FEAT256")) { // four rows per wave instruction
+        if (a.nq <= 512) {
+            if (a.allow) return launch_one(beam_search_feat256_filtered_kernel<1, 16>, 16 * 64, lds, g, a, st);
+            return launch_one(beam_search_feat256_kernel<1, 16>, 16 * 64, lds, g, a, st);
+        }
+        if (a.allow) return launch_one(beam_search_feat256_filtered_kernel<LEANN_FEAT_G, 4>, 4 * 64, lds, g, a, st);
+        return launch_one(beam_search_feat256_kernel<LEANN_FEAT_G, 4>, 4 * 64, lds, g, a, st);
+    }
     if (a.nq <= 512) {
         if (a.allow) return launch_one(beam_search_feat_filtered_kernel<T, R, 16>, 16 * 64, lds, g, a, st);
         return launch_one(beam_search_feat_kernel<T, R, 16>, 16 * 64, lds, g, a, st);

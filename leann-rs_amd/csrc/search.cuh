@@ -70,6 +70,20 @@ struct SearchArgs {
     uint64_t allow_stride;    // ... of query i at allow + i * allow_stride (0: one bitmap shared by the batch)
 };
 
+// The traversal kernels all take (GraphView g, SearchArgs a) by value.  Two dozen of `a`'s fields are needed only by rare paths (visited
+// set migration, expansion trace) or once at the end (outputs); read through the by-value struct they are loaded at kernel entry and
+// stay live — in scalar registers the hop loop is short of (it spilled 70 of them into vector lanes) — to the last line.  Read from
+// the kernel-argument segment at the point of use they cost one scalar load there and nothing in between.
+__device__ __forceinline__ const __attribute__((address_space(4))) SearchArgs *lazy_search_args() {
+    typedef const __attribute__((address_space(4))) char *kptr;
+    return (const __attribute__((address_space(4))) SearchArgs *)((kptr)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                                  ((sizeof(GraphView) + 7) & ~(size_t)7));
+}
+
+// A value every lane read from the same LDS word: tell the compiler it is uniform, so that it and everything derived from it (beam
+// size, buffer pointers, loop bounds) live in scalar registers instead of one vector register each.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 __device__ __forceinline__ uint32_t vis_hash(uint32_t id, uint32_t bits) {
     return (id * 0x9E3779B1u) >> (32 - bits);
 }
@@ -161,6 +175,59 @@ __device__ __forceinline__ void wave_dist_rows_feat(const float4 (&q)[T], const 
     }
 }
 
+// Recompute-on rows of exactly 256 bf16 features (+ inline norm), FOUR passages per wave instruction: the 16 lanes of a DPP row share a
+// passage, lane m of them owns elements 8m..8m+7 and 128+8m..128+8m+7 (two 16-byte loads; each instruction reads a contiguous 256-B
+// half of four rows), and one pass of the DPP ladder reduces four rows at once — against one row per 8-byte wave load and one
+// six-step ladder per row above.  G such groups in flight per wave.  The sum is the SAME balanced tree over the 64 four-element
+// partials (partial v = elements 4v..4v+3, lane m holds partials 2m, 2m+1, 32+2m, 32+2m+1): level 1 and level 6 are additions inside
+// the lane, levels 2-5 run on the row's DPP ladder — every pairing is wave_tree_sum's, so the distances are bit-identical.
+// Results (and the norm load) live in lane 15 of each DPP row.
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ float feat8_partial_pair(const float (&q)[8], const u32x4_a8 v) {
+    float4 lo, hi;
+    lo.x = fmaf(q[0], __uint_as_float(v.x << 16), 0.f);
+    lo.y = fmaf(q[1], __uint_as_float(v.x & 0xFFFF0000u), 0.f);
+    lo.z = fmaf(q[2], __uint_as_float(v.y << 16), 0.f);
+    lo.w = fmaf(q[3], __uint_as_float(v.y & 0xFFFF0000u), 0.f);
+    hi.x = fmaf(q[4], __uint_as_float(v.z << 16), 0.f);
+    hi.y = fmaf(q[5], __uint_as_float(v.z & 0xFFFF0000u), 0.f);
+    hi.z = fmaf(q[6], __uint_as_float(v.w << 16), 0.f);
+    hi.w = fmaf(q[7], __uint_as_float(v.w & 0xFFFF0000u), 0.f);
+    return lane4_sum(lo) + lane4_sum(hi); // level 1: partials 2m and 2m + 1
+}
+template <int G>
+__device__ __forceinline__ void group_dist_rows_feat256(const float (&qa)[8], const float (&qb)[8], const char *__restrict__ Xb,
+                                                        uint32_t row_bytes, const uint32_t (&id)[G], const bool (&valid)[G], int lane,
+                                                        float (&out)[G]) {
+    const int m = lane & 15;
+    u32x4_a8 va[G], vb[G];
+    float nrm[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        va[g] = vb[g] = u32x4_a8{0u, 0u, 0u, 0u};
+        nrm[g] = 1.f;
+        if (valid[g]) {
+            const char *row = Xb + (size_t)id[g] * row_bytes;
+            va[g] = *reinterpret_cast<const u32x4_a8 *>(row + 16 * m);
+            vb[g] = *reinterpret_cast<const u32x4_a8 *>(row + 256 + 16 * m);
+            if (m == 15) nrm[g] = *reinterpret_cast<const float *>(row + 512);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        float sa = feat8_partial_pair(qa, va[g]), sb = feat8_partial_pair(qb, vb[g]);
+        sa = dpp_pair_add<0xB1, 0xf>(sa);  // level 2: lane ^ 1
+        sb = dpp_pair_add<0xB1, 0xf>(sb);
+        sa = dpp_pair_add<0x4E, 0xf>(sa);  // level 3: lane ^ 2
+        sb = dpp_pair_add<0x4E, 0xf>(sb);
+        sa = dpp_pair_add<0x114, 0xf>(sa); // level 4: row_shr:4
+        sb = dpp_pair_add<0x114, 0xf>(sb);
+        sa = dpp_pair_add<0x118, 0xf>(sa); // level 5: row_shr:8 -> lanes 12..15 of the row: partials 0..31 / 32..63
+        sb = dpp_pair_add<0x118, 0xf>(sb);
+        out[g] = 1.0f - (sa + sb) / nrm[g]; // level 6
+    }
+}
+
 // neighbour list of `node` on level lv: level 0 lists are [n x M0], upper lists [n_upper_lists x M] at upper_off[node] + lv - 1
 __device__ __forceinline__ const uint32_t *adj_list(const uint32_t *__restrict__ base, const uint32_t *__restrict__ upper_off, uint32_t deg,
                                                     int lv, uint32_t node) {
@@ -187,9 +254,12 @@ __host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg,
     return b + ((size_t)1 << hash_bits) * 4;
 }
 
-template <int T, int R, int NW, bool FEAT, bool FILT = false>
+// G16 (recompute-on rows of 256 features only): phase C evaluates four rows per wave instruction (group_dist_rows_feat256), R = groups
+// in flight per wave.
+template <int T, int R, int NW, bool FEAT, bool FILT = false, bool G16 = false>
 __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_t qi, unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const auto *const za = lazy_search_args(); // arguments of the rare paths and of the epilogue: read where they are used
     const uint32_t ef = a.ef;
     const uint32_t maxdeg = g.M0 > g.M ? g.M0 : g.M;
     const uint32_t efp = (ef + 1) & ~1u;
@@ -219,13 +289,22 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
 
     // ---- query into registers -----------------------------------------------------------------
     float4 q[T];
+    float qa[8], qb[8]; // G16: elements 8m..8m+7 and 128+8m..+7 of the query, m = lane within the DPP row
     {
         const float *qv;
         uint32_t dq = FEAT ? g.feat_h : g.d;
         if (!FEAT && a.q_rows) qv = g.X + (size_t)a.q_rows[qi] * g.ld;
         else qv = a.queries + (size_t)qi * a.ldq;
 #pragma unroll
-        for (int t = 0; t < T; t++) q[t] = vec_load4_guard(qv, dq, t, lane);
+        for (int t = 0; t < T; t++)
+            if (!G16) q[t] = vec_load4_guard(qv, dq, t, lane);
+        if (G16) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                qa[i] = qv[8 * (lane & 15) + i];
+                qb[i] = qv[128 + 8 * (lane & 15) + i];
+            }
+        }
     }
 
     const uint32_t *const adj0_p = g.adj0, *const adjU_p = g.adjU, *const upoff_p = g.upper_off;
@@ -235,7 +314,11 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     {
         uint32_t ids[1] = {g.entry};
         float dd[1];
-        if (FEAT) wave_dist_rows_feat<T, 1>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, 1, lane, dd);
+        if (G16) {
+            const bool valid[1] = {lane < 16};
+            group_dist_rows_feat256<1>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd);
+            dd[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dd[0]), 15));
+        } else if (FEAT) wave_dist_rows_feat<T, 1>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, 1, lane, dd);
         else wave_dist_rows<T, 1>(q, g.X, g.ld, ids, 1, lane, dd);
         best = make_key(dd[0], g.entry); // every wave computes the same value
     }
@@ -255,7 +338,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         if (tid == 0) {
             W0[0] = best;
             if (hbm) {
-                gen = atomicAdd(&a.gpool_ctr[1], 1u) + 1u;
+                gen = atomicAdd(&za->gpool_ctr[1], 1u) + 1u;
                 s.misc[5] = gen;
                 vis_insert_hbm(gtab, gbits, gen, key_id(best));
             } else {
@@ -272,9 +355,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
             }
         }
         __syncthreads();
-        if (hbm) gen = s.misc[5];
+        if (hbm) gen = uni(s.misc[5]);
         const bool filt_level = FILT && lv == (int)a.target_level;
-        if (filt_level) { rsize = s.misc[6]; rcur = 0; }
+        if (filt_level) { rsize = uni(s.misc[6]); rcur = 0; }
         cur = 0;
         wsize = 1;
         n_vis = 1;
@@ -304,8 +387,8 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 // ---- phase B: adjacency list through the visited table (wave 0) ------------------
                 if (wave == 0) {
                     const uint32_t node = key_id(Wc[sel]);
-                    if (a.out_expanded && lv == (int)a.target_level && lane == 0 && hop < a.exp_cap)
-                        a.out_expanded[(size_t)qi * a.exp_cap + hop] = ((Wc[sel] >> 32) << 32) | node;
+                    if (za->out_expanded && lv == (int)a.target_level && lane == 0 && hop < za->exp_cap)
+                        za->out_expanded[(size_t)qi * za->exp_cap + hop] = ((Wc[sel] >> 32) << 32) | node;
                     uint32_t n_new = 0;
                     bool ovf = (n_vis + deg > vis_limit);
                     if (!ovf) {
@@ -334,31 +417,31 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     #ifdef LEANN_STAMPS
                 const uint64_t stB1 = __builtin_amdgcn_s_memtime();
     #endif
-                const uint32_t table_full = s.misc[3];
+                const uint32_t table_full = uni(s.misc[3]);
                 if (table_full) {
                     // Table full: move the visited set one level up (LDS -> pool 1 -> pool 2) and redo this hop.
                     const uint32_t next = hbm + 1;
-                    if (next > 2 || (next == 2 && !a.gpool2)) { aborted = true; break; } // defensive: see the pool comment above
+                    if (next > 2 || (next == 2 && !za->gpool2)) { aborted = true; break; } // defensive: see the pool comment above
                     __syncthreads(); // every thread has read the flag before it is cleared
                     if (tid == 0) {
-                        uint32_t *locks = next == 1 ? a.gpool_lock : a.gpool2_lock;
-                        const uint32_t ntab = next == 1 ? a.gpool_tables : a.gpool2_tables;
-                        uint32_t t = atomicAdd(&a.gpool_ctr[next == 1 ? 0 : 2], 1u), slot;
+                        uint32_t *locks = next == 1 ? za->gpool_lock : za->gpool2_lock;
+                        const uint32_t ntab = next == 1 ? za->gpool_tables : za->gpool2_tables;
+                        uint32_t t = atomicAdd(&za->gpool_ctr[next == 1 ? 0 : 2], 1u), slot;
                         for (uint32_t i = 0;; i++) { // holders never wait for anything, so a table always comes free
                             slot = (t + i) % ntab;
                             if (atomicCAS(&locks[slot], 0u, 1u) == 0u) break;
                             if ((i % ntab) == ntab - 1) __builtin_amdgcn_s_sleep(32);
                         }
                         s.misc[4] = slot;
-                        if (!hbm) s.misc[5] = atomicAdd(&a.gpool_ctr[1], 1u) + 1u; // pool 1 -> 2 keeps the generation
+                        if (!hbm) s.misc[5] = atomicAdd(&za->gpool_ctr[1], 1u) + 1u; // pool 1 -> 2 keeps the generation
                         s.misc[3] = 0;
                     }
                     __syncthreads();
-                    const uint32_t nslot = s.misc[4];
-                    const uint32_t nbits = next == 1 ? a.gpool_bits : a.gpool2_bits;
-                    unsigned long long *ntab_p = (next == 1 ? a.gpool : a.gpool2) + ((size_t)nslot << nbits);
+                    const uint32_t nslot = uni(s.misc[4]);
+                    const uint32_t nbits = next == 1 ? za->gpool_bits : za->gpool2_bits;
+                    unsigned long long *ntab_p = (next == 1 ? za->gpool : za->gpool2) + ((size_t)nslot << nbits);
                     if (!hbm) {
-                        gen = s.misc[5];
+                        gen = uni(s.misc[5]);
                         for (uint32_t i = tid; i < hsize; i += NW * 64) {
                             uint32_t e = table[i];
                             if (e != LEANN_EMPTY) vis_insert_hbm(ntab_p, nbits, gen, e);
@@ -369,7 +452,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                             if ((uint32_t)(cur >> 32) == gen) vis_insert_hbm(ntab_p, nbits, gen, (uint32_t)cur);
                         }
                         __syncthreads(); // every probe of the old table has returned
-                        if (tid == 0) atomicExch(&a.gpool_lock[gslot], 0u);
+                        if (tid == 0) atomicExch(&za->gpool_lock[gslot], 0u);
                     }
                     gtab = ntab_p;
                     gbits = nbits;
@@ -379,8 +462,32 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     __syncthreads();
                     continue;
                 }
-                const uint32_t n_new = s.misc[0];
+                const uint32_t n_new = uni(s.misc[0]);
                 // ---- phase C: stream the new rows, R in flight per wave ------------------------------
+                if constexpr (G16) {
+                    for (uint32_t jb = 0; jb < n_new; jb += NW * 4 * R) {
+                        uint32_t ids[R], jj[R], abyte[R];
+                        bool valid[R];
+                        float dd[R];
+    #pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            jj[r] = jb + (uint32_t)(r * NW + wave) * 4u + (uint32_t)(lane >> 4);
+                            valid[r] = jj[r] < n_new;
+                            ids[r] = valid[r] ? s.s_new[jj[r]] : 0u;
+                            abyte[r] = (filt_level && valid[r] && (lane & 15) == 15) ? allow[ids[r] >> 3] : 0u;
+                        }
+                        group_dist_rows_feat256<R>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd);
+                        if ((lane & 15) == 15) {
+    #pragma unroll
+                            for (int r = 0; r < R; r++)
+                                if (valid[r]) {
+                                    const uint64_t key = make_key(dd[r], ids[r]);
+                                    s.s_key[jj[r]] = key;
+                                    if (filt_level) s_keyR[jj[r]] = ((abyte[r] >> (ids[r] & 7u)) & 1u) ? key : ~0ull;
+                                }
+                        }
+                    }
+                } else
                 for (uint32_t j0 = wave; j0 < n_new; j0 += NW * R) {
                     uint32_t ids[R];
                     float dd[R];
@@ -528,7 +635,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     stamp[4] += stD - stB2; stamp[5] += stE - stD; stamp[6] += 1;
                 }
     #endif
-                sel = *next_slot;
+                sel = uni(*next_slot);
                 wsize = min(wsize + n_new, ef_l);
                 cur ^= 1;
                 hop++;
@@ -549,8 +656,8 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                 uint64_t *skey = s.s_key + p * kstride;
                 uint32_t *snew = s.s_new + p * maxdeg;
                 const uint32_t node = key_id(ckey);
-                if (a.out_expanded && lv == (int)a.target_level && lane == 0 && hidx < a.exp_cap)
-                    a.out_expanded[(size_t)qi * a.exp_cap + hidx] = ((ckey >> 32) << 32) | node;
+                if (za->out_expanded && lv == (int)a.target_level && lane == 0 && hidx < za->exp_cap)
+                    za->out_expanded[(size_t)qi * za->exp_cap + hidx] = ((ckey >> 32) << 32) | node;
                 uint32_t n_new = 0;
                 const bool ovf = (n_vis + deg > vis_limit);
                 if (!ovf) {
@@ -583,30 +690,30 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
 #ifdef LEANN_STAMPS // diagnostic build only (scripts/stamps.sh): where does a hop spend its cycles?
                 const uint64_t st0 = __builtin_amdgcn_s_memtime();
 #endif
-                if (s.misc[3]) {
+                if (uni(s.misc[3])) {
                     // Table full: move the visited set one level up (LDS -> pool 1 -> pool 2), then wave 0 prepares this hop again.
                     const uint32_t next = hbm + 1;
-                    if (next > 2 || (next == 2 && !a.gpool2)) { aborted = true; break; } // defensive: see the pool comment above
+                    if (next > 2 || (next == 2 && !za->gpool2)) { aborted = true; break; } // defensive: see the pool comment above
                     __syncthreads(); // every thread has read the flag before it is cleared
                     if (tid == 0) {
-                        uint32_t *locks = next == 1 ? a.gpool_lock : a.gpool2_lock;
-                        const uint32_t ntab = next == 1 ? a.gpool_tables : a.gpool2_tables;
-                        uint32_t t = atomicAdd(&a.gpool_ctr[next == 1 ? 0 : 2], 1u), slot;
+                        uint32_t *locks = next == 1 ? za->gpool_lock : za->gpool2_lock;
+                        const uint32_t ntab = next == 1 ? za->gpool_tables : za->gpool2_tables;
+                        uint32_t t = atomicAdd(&za->gpool_ctr[next == 1 ? 0 : 2], 1u), slot;
                         for (uint32_t i = 0;; i++) { // holders never wait for anything, so a table always comes free
                             slot = (t + i) % ntab;
                             if (atomicCAS(&locks[slot], 0u, 1u) == 0u) break;
                             if ((i % ntab) == ntab - 1) __builtin_amdgcn_s_sleep(32);
                         }
                         s.misc[4] = slot;
-                        if (!hbm) s.misc[5] = atomicAdd(&a.gpool_ctr[1], 1u) + 1u; // pool 1 -> 2 keeps the generation
+                        if (!hbm) s.misc[5] = atomicAdd(&za->gpool_ctr[1], 1u) + 1u; // pool 1 -> 2 keeps the generation
                         s.misc[3] = 0;
                     }
                     __syncthreads();
-                    const uint32_t nslot = s.misc[4];
-                    const uint32_t nbits = next == 1 ? a.gpool_bits : a.gpool2_bits;
-                    unsigned long long *ntab_p = (next == 1 ? a.gpool : a.gpool2) + ((size_t)nslot << nbits);
+                    const uint32_t nslot = uni(s.misc[4]);
+                    const uint32_t nbits = next == 1 ? za->gpool_bits : za->gpool2_bits;
+                    unsigned long long *ntab_p = (next == 1 ? za->gpool : za->gpool2) + ((size_t)nslot << nbits);
                     if (!hbm) {
-                        gen = s.misc[5];
+                        gen = uni(s.misc[5]);
                         for (uint32_t i = tid; i < hsize; i += NW * 64) {
                             uint32_t e = table[i];
                             if (e != LEANN_EMPTY) vis_insert_hbm(ntab_p, nbits, gen, e);
@@ -617,7 +724,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                             if ((uint32_t)(cur_e >> 32) == gen) vis_insert_hbm(ntab_p, nbits, gen, (uint32_t)cur_e);
                         }
                         __syncthreads(); // every probe of the old table has returned
-                        if (tid == 0) atomicExch(&a.gpool_lock[gslot], 0u);
+                        if (tid == 0) atomicExch(&za->gpool_lock[gslot], 0u);
                     }
                     gtab = ntab_p;
                     gbits = nbits;
@@ -629,11 +736,44 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     __syncthreads();
                     continue;
                 }
-                const uint32_t n_new = s.misc[8 + par];
+                const uint32_t n_new = uni(s.misc[8 + par]);
                 uint64_t *const skey = s.s_key + par * kstride;
                 const uint32_t *const snew = s.s_new + par * maxdeg;
                 uint64_t *const skeyR = s_keyR + par * kstride;
                 // ---- phase C: stream the new rows, R in flight per wave ------------------------------
+                if constexpr (G16) {
+                    for (uint32_t jb = 0; jb < n_new; jb += NW * 4 * R) {
+                        uint32_t ids[R], jj[R], abyte[R];
+                        bool valid[R];
+                        float dd[R];
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            jj[r] = jb + (uint32_t)(r * NW + wave) * 4u + (uint32_t)(lane >> 4);
+                            valid[r] = jj[r] < n_new;
+                            ids[r] = valid[r] ? snew[jj[r]] : 0u;
+                            abyte[r] = (filt_level && valid[r] && (lane & 15) == 15) ? allow[ids[r] >> 3] : 0u;
+                        }
+#ifndef LEANN_NO_ADJ_TOUCH
+                        // adjacency lists of the rows being evaluated (see the row-per-wave form below): lanes 12, 13 of a row touch
+                        uint32_t touch = 0;
+                        if (lv == 0 && valid[0] && (lane & 14) == 12 && (uint32_t)(lane & 1) * 32u < deg)
+                            touch = adj0_p[(size_t)ids[0] * deg + (uint32_t)(lane & 1) * 32u];
+#endif
+                        group_dist_rows_feat256<R>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd);
+#ifndef LEANN_NO_ADJ_TOUCH
+                        asm volatile("" ::"v"(touch));
+#endif
+                        if ((lane & 15) == 15) {
+#pragma unroll
+                            for (int r = 0; r < R; r++)
+                                if (valid[r]) {
+                                    const uint64_t key = make_key(dd[r], ids[r]);
+                                    skey[jj[r]] = key;
+                                    if (filt_level) skeyR[jj[r]] = ((abyte[r] >> (ids[r] & 7u)) & 1u) ? key : ~0ull;
+                                }
+                        }
+                    }
+                } else
                 for (uint32_t j0 = wave; j0 < n_new; j0 += NW * R) {
                     uint32_t ids[R];
                     float dd[R];
@@ -793,7 +933,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     stamp[4] += stD - stB2; stamp[5] += stE - stD; stamp[6] += 1;
                 }
 #endif
-                sel = *next_slot;
+                sel = uni(*next_slot);
                 wsize = min(wsize + n_new, ef_l);
                 cur ^= 1;
                 hop++;
@@ -809,50 +949,50 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
 
     // ---- results ------------------------------------------------------------------------------
     __syncthreads();
-    if (hbm && tid == 0) atomicExch(&(hbm == 1 ? a.gpool_lock : a.gpool2_lock)[gslot], 0u); // every probe of this workgroup has returned
+    if (hbm && tid == 0) atomicExch(&(hbm == 1 ? za->gpool_lock : za->gpool2_lock)[gslot], 0u); // every probe of this workgroup has returned
     if (aborted) { // defensive (see the pool comment): the last table level filled up; empty result + stat 3 -> LEANN_ERR_OVERFLOW
-        for (uint32_t t = tid; t < a.k; t += NW * 64) {
-            a.out_keys[(size_t)qi * a.k + t] = 0xFFFFFFFFFFFFFFFFull;
-            a.out_dists[(size_t)qi * a.k + t] = __uint_as_float(0x7F800000u);
+        for (uint32_t t = tid; t < za->k; t += NW * 64) {
+            za->out_keys[(size_t)qi * za->k + t] = 0xFFFFFFFFFFFFFFFFull;
+            za->out_dists[(size_t)qi * za->k + t] = __uint_as_float(0x7F800000u);
         }
         if (tid == 0) {
-            a.out_counts[qi] = 0;
-            if (a.out_stats) {
-                a.out_stats[(size_t)qi * 4 + 0] = n_evals;
-                a.out_stats[(size_t)qi * 4 + 1] = hops0;
-                a.out_stats[(size_t)qi * 4 + 2] = hopsU;
-                a.out_stats[(size_t)qi * 4 + 3] = 3u;
+            za->out_counts[qi] = 0;
+            if (za->out_stats) {
+                za->out_stats[(size_t)qi * 4 + 0] = n_evals;
+                za->out_stats[(size_t)qi * 4 + 1] = hops0;
+                za->out_stats[(size_t)qi * 4 + 2] = hopsU;
+                za->out_stats[(size_t)qi * 4 + 3] = 3u;
             }
         }
         return;
     }
-    const uint32_t nout = FILT ? rsize : min(wsize, a.k);
+    const uint32_t nout = FILT ? rsize : min(wsize, za->k);
     uint64_t *Wc = FILT ? R0 + rcur * kfp : W0 + cur * efp;
-    for (uint32_t t = tid; t < a.k; t += NW * 64) {
-        size_t o = (size_t)qi * a.k + t;
+    for (uint32_t t = tid; t < za->k; t += NW * 64) {
+        size_t o = (size_t)qi * za->k + t;
         if (t < nout) {
             uint64_t k = Wc[t];
-            a.out_keys[o] = (uint64_t)key_id(k) + a.key_offset;
-            a.out_dists[o] = key_dist(k);
+            za->out_keys[o] = (uint64_t)key_id(k) + za->key_offset;
+            za->out_dists[o] = key_dist(k);
         } else {
-            a.out_keys[o] = 0xFFFFFFFFFFFFFFFFull;
-            a.out_dists[o] = __uint_as_float(0x7F800000u);
+            za->out_keys[o] = 0xFFFFFFFFFFFFFFFFull;
+            za->out_dists[o] = __uint_as_float(0x7F800000u);
         }
     }
 #ifdef LEANN_STAMPS
-    if (tid == 0 && a.out_expanded == nullptr && a.exp_cap == 0xFEED) { // stamps go to a buffer of their own (passed via out_nexp)
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.out_nexp) + (size_t)qi * 8;
+    if (tid == 0 && za->out_expanded == nullptr && za->exp_cap == 0xFEED) { // stamps go to a buffer of their own (passed via out_nexp)
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(za->out_nexp) + (size_t)qi * 8;
         for (int i = 0; i < 7; i++) dst[i] = stamp[i];
     }
 #endif
     if (tid == 0) {
-        a.out_counts[qi] = nout;
-        if (a.out_nexp && a.exp_cap != 0xFEED) a.out_nexp[qi] = min(level_hops, a.exp_cap);
-        if (a.out_stats) {
-            a.out_stats[(size_t)qi * 4 + 0] = n_evals;
-            a.out_stats[(size_t)qi * 4 + 1] = hops0;
-            a.out_stats[(size_t)qi * 4 + 2] = hopsU;
-            a.out_stats[(size_t)qi * 4 + 3] = hbm; // 0 LDS table only, 1 / 2 the visited set moved to pool 1 / 2
+        za->out_counts[qi] = nout;
+        if (za->out_nexp && za->exp_cap != 0xFEED) za->out_nexp[qi] = min(level_hops, za->exp_cap);
+        if (za->out_stats) {
+            za->out_stats[(size_t)qi * 4 + 0] = n_evals;
+            za->out_stats[(size_t)qi * 4 + 1] = hops0;
+            za->out_stats[(size_t)qi * 4 + 2] = hopsU;
+            za->out_stats[(size_t)qi * 4 + 3] = hbm; // 0 LDS table only, 1 / 2 the visited set moved to pool 1 / 2
         }
     }
     __syncthreads();
@@ -893,6 +1033,30 @@ __global__ void __launch_bounds__(NW * 64) beam_search_feat_filtered_kernel(Grap
 #ifndef LEANN_FEAT_R1
 #define LEANN_FEAT_R1 5
 #endif
+// recompute-on rows of exactly 256 features: four rows per wave instruction, G groups in flight per wave (G16 above).  Throughput
+// shape = 6 workgroups per CU x 2 groups (32 rows per workgroup and round: a typical hop's ~26 unseen neighbours in ONE round): 4.31 M
+// queries/s at ef = 52 = 7.6 G random rows/s, the rate scripts/micro/gather_bw.hip measures as the memory system's ceiling for 520-B
+// rows.  8 workgroups per CU (64 registers) spill: 3.7 M; 7 x 1 group = 6 x 2; 6 x 3 groups 3.5 M (scripts/exp/feat256_shape.sh).
+#ifndef LEANN_FEAT_G
+#define LEANN_FEAT_G 2
+#endif
+#ifndef LEANN_FEAT256_OCC
+#define LEANN_FEAT256_OCC 6
+#endif
+template <int G, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? LEANN_FEAT256_OCC : 1) beam_search_feat256_kernel(GraphView g, SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    beam_search_one<1, G, NW, true, false, true>(g, a, qi, smem);
+}
+template <int G, int NW>
+__global__ void __launch_bounds__(NW * 64) beam_search_feat256_filtered_kernel(GraphView g, SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    beam_search_one<1, G, NW, true, true, true>(g, a, qi, smem);
+}
 // recompute-on instantiation: rows are bf16 features + inline norm, queries are W q
 template <int T, int R, int NW>
 __global__ void __launch_bounds__(NW * 64, (NW == 4 && T == 1) ? LEANN_FEAT_OCC : 1) beam_search_feat_kernel(GraphView g, SearchArgs a) {

@@ -109,14 +109,16 @@ def test_in_traversal_filter_beats_post_filter(la, po, gpu):
     s.close()
 
 
-def test_filtered_recompute_on_graph(la, po, gpu):
-    """feature-row (no stored vectors) instantiation of the filtered kernel vs the oracle over the same bytes"""
+@pytest.mark.parametrize("nq", [64, 600])
+def test_filtered_recompute_on_graph(la, po, gpu, nq):
+    """feature-row (no stored vectors) instantiation of the filtered kernel vs the oracle over the same bytes
+    (64 queries: 16 waves per query; 600: the 4-wave throughput form)"""
     n, h, d, M, k = 6000, 256, 768, 16, 10
     rng = np.random.default_rng(3)
     Lc, chk = la.lib(), la._native.check
     F = po.synth_features(SEED, h, 64, 1.0, 0, 0, n)
     W = po.synth_weights(SEED, h, d)
-    Q = po.recompute_encode(po.synth_features(SEED, h, 64, 1.0, 1, 0, 64), W)
+    Q = po.recompute_encode(po.synth_features(SEED, h, 64, 1.0, 1, 0, nq), W)
     dF, dW = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W)
     r = C.c_void_p()
     chk(Lc.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))

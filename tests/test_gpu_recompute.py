@@ -124,12 +124,15 @@ def test_masked_mean_pooling_provider(la, po, gpu, L):
     Lc.leann_recompute_close(r)
 
 
-def test_recompute_on_graph_search(la, po, gpu):
+@pytest.mark.parametrize("nq,h", [(200, 256), (700, 256), (700, 128), (130, 128)])
+def test_recompute_on_graph_search(la, po, gpu, nq, h):
     """Graph index with NO stored vectors: distances recomputed from bf16 features, dist = 1 - <f, W q> / ||W^T f||.
     (a) GPU traversal == oracle traversal over the same bytes, bit for bit; (b) same neighbours as the stored-vector
-    index built from the materialised embeddings (scores within 1e-5); (c) recall vs exact search."""
+    index built from the materialised embeddings (scores within 1e-5); (c) recall vs exact search.
+    Batches of <= 512 queries run the 16-waves-per-query form, larger ones the 4-wave form; rows of exactly 256 features are read
+    four per wave instruction (search.cuh: group_dist_rows_feat256), other widths one per wave load — all four against the oracle."""
     from util import recall_at_k
-    n, h, d, nq, k = 20000, 256, 768, 200, 10
+    n, d, k = 20000, 768, 10
     Lc, chk = la.lib(), la._native.check
     F = po.synth_features(SEED, h, 64, 1.0, 0, 0, n)
     W = po.synth_weights(SEED, h, d)
@@ -142,14 +145,14 @@ def test_recompute_on_graph_search(la, po, gpu):
     s = la.BackendSearcher(hb, la.BackendType.Hnsw)
     fh, rb = C.c_uint32(0), C.c_uint32(0)
     chk(Lc.leann_backend_feature_rows_export(hb, C.byref(fh), C.byref(rb), None))
-    assert fh.value == 256 and rb.value == 520
+    assert fh.value == h and rb.value == 2 * h + 8
     rows = np.zeros((n, rb.value), np.uint8)
     chk(Lc.leann_backend_feature_rows_export(hb, None, None, rows.ctypes.data))
-    assert (rows[:, :512].view(np.uint16) == F).all()
+    assert (rows[:, : 2 * h].view(np.uint16) == F).all()
     s.stats(reset=True)
     gk, gd, gc = s.search_batch(Q, k, 64)
     st = s.stats()
-    assert st["algorithmic_bytes"] < st["n_dist_evals"] * 600  # 520 B per evaluated neighbour, not 3 072
+    assert st["algorithmic_bytes"] < st["n_dist_evals"] * 600  # 2 h + 8 B per evaluated neighbour, not 3 072
     # (a) oracle over the same graph + feature bytes + projected queries
     g = s.graph_export()
     Gr = po.Graph.from_arrays(np.zeros((n, 1), np.float32), 16, 32, g["max_level"], g["entry"], g["levels"], g["upper_off"],
