@@ -100,7 +100,7 @@ Files: `r02_hnsw10m_kernel_stats.csv` (every kernel of the process incl. index c
 def other_kernels():
     """profiles/r02_other_kernels.md: the kernels of the side workloads (scripts/profile_side.sh)"""
     lines = ["# Round 2 — other kernels (1x MI355X; rocprofv3 --kernel-trace --stats of `bench.py --workload … --no-cpu-baseline --no-latency`)", ""]
-    for wl, pat in (("recompute10m_graph", "beam_search_feat_kernel"), ("recompute10m", "fused_fstat_kernel")):
+    for wl, pat in (("recompute10m_graph", "beam_search_feat256_kernel"), ("recompute10m", "fused_fstat_kernel")):
         pj, pc = os.path.join(src, f"prof_{wl}.json"), os.path.join(src, f"prof_{wl}", "r02_kernel_stats.csv")
         if not (os.path.exists(pj) and os.path.exists(pc)):
             continue
@@ -113,7 +113,7 @@ def other_kernels():
             lines.append(f"* kernel-stats row `{x['Name'][:60]}`: Calls {x['Calls']}, AverageNs {float(x['AverageNs']):.0f}, MinNs {x['MinNs']}, MaxNs {x['MaxNs']}")
         if wl == "recompute10m_graph":
             lines.append(f"* bench.py HIP-event average of the timed launches: {r['kernel_avg_ms']:.3f} ms; algorithmic bytes per query {r['algorithmic_bytes_per_query']:.0f} "
-                         f"({r['dist_evals_per_query']:.0f} evaluations x 520 B + {r['hops_per_query']:.0f} hops x 256 B); ceiling for random 520-B rows: 3.9-4.0 TB/s (`r02_gather_ceiling.txt`)")
+                         f"({r['dist_evals_per_query']:.0f} evaluations x 520 B + {r['hops_per_query']:.0f} hops x 256 B); ceiling for random 520-B rows read four per instruction: 10 G rows/s = 5.2 TB/s algorithmic = 6.4 TB/s in whole 128-B lines (`r02_gather_ceiling.txt`)")
         lines.append("")
     pm = os.path.join(src, "prof_mfma", "r02_counter_collection.csv")
     if os.path.exists(pm):
