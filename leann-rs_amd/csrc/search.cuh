@@ -324,7 +324,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
     }
 
 #ifdef LEANN_STAMPS
-    uint64_t stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // [7]: hops whose next candidate came from the OLD beam (not from the hop's new keys)
 #endif
     uint32_t wsize = 0, level_hops = 0;
     int cur = 0;
@@ -548,6 +548,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                         if ((c_old >> 1) < (c_new >> 1)) {
                             rank = u + (uint32_t)__popcll(__ballot((kj >> 1) < (c_old >> 1)));
                             cnode = key_id(c_old);
+    #ifdef LEANN_STAMPS
+                            stamp[7] += 1;
+    #endif
                         } else {
                             rank = 0;
                             for (uint32_t base = 0; base < wsize; base += 64) {
@@ -844,6 +847,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                         if ((c_old >> 1) < (c_new >> 1)) {
                             rank = u + (uint32_t)__popcll(__ballot((kj >> 1) < (c_old >> 1)));
                             ckey = c_old;
+#ifdef LEANN_STAMPS
+                            stamp[7] += 1;
+#endif
                         } else {
                             rank = 0;
                             for (uint32_t base = 0; base < wsize; base += 64) {
@@ -982,7 +988,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
 #ifdef LEANN_STAMPS
     if (tid == 0 && za->out_expanded == nullptr && za->exp_cap == 0xFEED) { // stamps go to a buffer of their own (passed via out_nexp)
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(za->out_nexp) + (size_t)qi * 8;
-        for (int i = 0; i < 7; i++) dst[i] = stamp[i];
+        for (int i = 0; i < 8; i++) dst[i] = stamp[i];
     }
 #endif
     if (tid == 0) {

@@ -34,3 +34,4 @@ for nq in (16384, 64):
     print(f"nq={nq} ef={ef} feat={feat}: {hops/nq:.0f} hops/query, {tot/hops:.0f} cycles per hop (wave 0 view)")
     for i, nm in enumerate(names):
         print(f"   {nm:30s} {st[:, i].sum()/hops:8.0f} cycles  {st[:, i].sum()/tot*100:5.1f} %")
+    print(f"   next candidate taken from the old beam (not from the hop's new keys): {st[:, 7].sum()/hops*100:.1f} % of the hops")
