@@ -74,6 +74,7 @@ struct SearchArgs {
 // set migration, expansion trace) or once at the end (outputs); read through the by-value struct they are loaded at kernel entry and
 // stay live — in scalar registers the hop loop is short of (it spilled 70 of them into vector lanes) — to the last line.  Read from
 // the kernel-argument segment at the point of use they cost one scalar load there and nothing in between.
+static_assert(alignof(SearchArgs) == 8 && alignof(GraphView) == 8, "lazy_search_args assumes `a` sits at the 8-byte aligned offset behind `g`");
 __device__ __forceinline__ const __attribute__((address_space(4))) SearchArgs *lazy_search_args() {
     typedef const __attribute__((address_space(4))) char *kptr;
     return (const __attribute__((address_space(4))) SearchArgs *)((kptr)__builtin_amdgcn_kernarg_segment_ptr() +
