@@ -690,7 +690,7 @@ def main():
                              "that interface with no counter exposed on this pool, so the HBM / Infinity-Cache split is unmeasured "
                              "(profiles/r02_other_kernels.md)",
             "kernel": ("beam_search_filtered_kernel" if allow is not None else
-                       ("beam_search_feat256_kernel<2,4>" if B > 512 else "beam_search_feat256_kernel<1,16>") + " (+ score_mfma_kernel query projection)" if rgraph else
+                       ("beam_search_feat256_kernel<1,4>" if B > 512 else "beam_search_feat256_kernel<1,16>") + " (+ score_mfma_kernel query projection)" if rgraph else
                        "beam_search_kernel<3,4,4,false>" if ld == 768 else "beam_search_kernel"),
             "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_query": bytes_per_query,
             "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -1041,14 +1041,15 @@ __global__ void __launch_bounds__(NW * 64) beam_search_feat_filtered_kernel(Grap
 #define LEANN_FEAT_R1 5
 #endif
 // recompute-on rows of exactly 256 features: four rows per wave instruction, G groups in flight per wave (G16 above).  Throughput
-// shape = 6 workgroups per CU x 2 groups (32 rows per workgroup and round: a typical hop's ~26 unseen neighbours in ONE round): 4.31 M
-// queries/s at ef = 52 = 7.6 G random rows/s, the rate scripts/micro/gather_bw.hip measures as the memory system's ceiling for 520-B
-// rows.  8 workgroups per CU (64 registers) spill: 3.7 M; 7 x 1 group = 6 x 2; 6 x 3 groups 3.5 M (scripts/exp/feat256_shape.sh).
+// shape = 7 workgroups per CU x 1 group (72 registers, no spills; 16 rows per workgroup and round): 4.5 M queries/s at ef = 52 =
+// 7.9 G random rows/s, against the 10 G rows/s scripts/micro/gather_bw.hip measures as the memory system's ceiling for this access
+// shape.  6 workgroups x 2 groups (a typical hop's ~26 unseen neighbours in ONE round) is 2 % behind, 8 workgroups (64 registers) spill:
+// 3.7-3.9 M, 6 x 3 groups 3.5 M (scripts/exp/feat256_shape.sh).
 #ifndef LEANN_FEAT_G
-#define LEANN_FEAT_G 2
+#define LEANN_FEAT_G 1
 #endif
 #ifndef LEANN_FEAT256_OCC
-#define LEANN_FEAT256_OCC 6
+#define LEANN_FEAT256_OCC 7
 #endif
 template <int G, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? LEANN_FEAT256_OCC : 1) beam_search_feat256_kernel(GraphView g, SearchArgs a) {

@@ -112,6 +112,26 @@ def other_kernels():
         for x in rows:
             lines.append(f"* kernel-stats row `{x['Name'][:60]}`: Calls {x['Calls']}, AverageNs {float(x['AverageNs']):.0f}, MinNs {x['MinNs']}, MaxNs {x['MaxNs']}")
         if wl == "recompute10m_graph":
+            pf, pw = (os.path.join(src, f"prof_rg_{c}", "r02_counter_collection.csv") for c in ("FETCH_SIZE", "WRITE_SIZE"))
+            if os.path.exists(pf) and os.path.exists(pw):
+                try:
+                    bf = json.load(open(os.path.join(src, "prof_rg_FETCH_SIZE.json")))
+                    fe = sum(last_n(pf, "FETCH_SIZE", 4)) / 4 * 1024
+                    wr = sum(last_n(pw, "WRITE_SIZE", 4)) / 4 * 1024
+                    alg = bf["roofline"]["algorithmic_bytes_per_launch"]
+                    json.dump({"workload": wl, "ef_search": bf["config"]["ef_search"], "kernel": "beam_search_feat256_kernel<1,4>",
+                               "launch": "16384 queries, k=10, 10M x (256 bf16 features + f32 norm)", "round": 2, "fetch_bytes_raw": fe,
+                               "fetch_bytes_corrected_x2_gfx950": 2 * fe, "write_bytes": wr, "hbm_bytes_per_launch": 2 * fe + wr,
+                               "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (2 * fe + wr) / alg,
+                               "method": "separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE), --kernel-include-regex on the query kernel, last 4 launches of "
+                                         "`bench.py --workload recompute10m_graph --no-cpu-baseline --no-latency --steps 4 --warmup 1` (scripts/profile_side.sh); "
+                                         "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; a 520-B row at an 8-byte aligned offset touches 5.06 lines of 128 B = "
+                                         "648 B on average, i.e. 1.25 x its algorithmic bytes"},
+                              open(os.path.join(dst, f"pmc_traffic_{wl}.json"), "w"), indent=1)
+                    lines.append(f"* PMC (separate passes): FETCH_SIZE x 2 + WRITE_SIZE = {(2 * fe + wr) / 1e9:.2f} GB per launch = {(2 * fe + wr) / alg:.3f} x the algorithmic "
+                                 f"{alg / 1e9:.2f} GB (whole 128-B lines: a 520-B row touches 5.06 of them = 1.25 x) -> {(2 * fe + wr) / 1e9 / r['kernel_avg_ms']:.2f} TB/s of line traffic")
+                except Exception as e:  # noqa: BLE001
+                    lines.append(f"* PMC traffic pass: failed ({e})")
             lines.append(f"* bench.py HIP-event average of the timed launches: {r['kernel_avg_ms']:.3f} ms; algorithmic bytes per query {r['algorithmic_bytes_per_query']:.0f} "
                          f"({r['dist_evals_per_query']:.0f} evaluations x 520 B + {r['hops_per_query']:.0f} hops x 256 B); ceiling for random 520-B rows read four per instruction: 10 G rows/s = 5.2 TB/s algorithmic = 6.4 TB/s in whole 128-B lines (`r02_gather_ceiling.txt`)")
         lines.append("")
