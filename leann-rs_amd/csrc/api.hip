@@ -89,6 +89,7 @@ static void ws_free(Workspace *w) {
     (void)hipFree(w->d_counts);
     (void)hipFree(w->d_stats);
     (void)hipFree(w->d_allow);
+    if (w->pin) (void)hipHostFree(w->pin);
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }
@@ -566,9 +567,25 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
         cap = need;
         return 0;
     };
-    if (grow((void **)&w->d_q, w->cap_q, qf, 4) || grow((void **)&w->d_keys, w->cap_keys, no, 8) ||
+    // Small call on a plain handle: zero-copy through the workspace's pinned block (internal.h).  Layout, 16-byte aligned pieces:
+    const size_t o_keys = (qf * 4 + 15) & ~(size_t)15, o_dists = o_keys + no * 8, o_counts = (o_dists + no * 4 + 15) & ~(size_t)15,
+                 o_stats = o_counts + ((nq * 4 + 15) & ~(size_t)15), pin_bytes = o_stats + nq * 16;
+    bool zero_copy = !h->sharded && !exact && pin_bytes <= ((size_t)256 << 10) && !getenv("LEANN_DEBUG_NO_ZERO_COPY");
+    if (zero_copy && w->cap_pin < pin_bytes) {
+        if (w->pin) (void)hipHostFree(w->pin);
+        w->pin = nullptr;
+        w->cap_pin = 0;
+        const size_t want = std::max<size_t>(pin_bytes, (size_t)64 << 10);
+        if (hipHostMalloc((void **)&w->pin, want, hipHostMallocDefault) == hipSuccess) w->cap_pin = want;
+        else { (void)hipGetLastError(); zero_copy = false; } // no pinned memory to be had: the staged path below
+    }
+    // (queries: read in place by up to 4 queries' workgroups — every wave of a query reads all of it, and mapped host memory is not
+    // cached on the device; larger small calls copy them from the pinned block with one DMA)
+    const bool zc_in = zero_copy && nq <= 4;
+    if (zero_copy && !zc_in && grow((void **)&w->d_q, w->cap_q, qf, 4)) return fail(LEANN_ERR_DEVICE);
+    if (!zero_copy && (grow((void **)&w->d_q, w->cap_q, qf, 4) || grow((void **)&w->d_keys, w->cap_keys, no, 8) ||
         grow((void **)&w->d_dists, w->cap_dists, no, 4) || grow((void **)&w->d_counts, w->cap_counts, nq, 4) ||
-        grow((void **)&w->d_stats, w->cap_stats, ns * nq * 4, 4))
+        grow((void **)&w->d_stats, w->cap_stats, ns * nq * 4, 4)))
         return fail(LEANN_ERR_DEVICE);
     hipStream_t st = w->stream;
     if (allow) {
@@ -586,21 +603,22 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
             return fail(LEANN_ERR_DEVICE);
         }
     }
-    if (hipMemcpyAsync(w->d_q, queries, qf * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+    if (zero_copy) memcpy(w->pin, queries, qf * 4);
+    if (!zc_in && hipMemcpyAsync(w->d_q, zero_copy ? reinterpret_cast<const float *>(w->pin) : queries, qf * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
         leann_set_error("H2D copy of queries failed");
         return fail(LEANN_ERR_DEVICE);
     }
     SearchArgs a{};
-    a.queries = w->d_q;
+    a.queries = zc_in ? reinterpret_cast<const float *>(w->pin) : w->d_q;
     a.ldq = (uint32_t)d;
     a.nq = (uint32_t)nq;
     a.k = (uint32_t)top_k;
     a.ef = (uint32_t)std::max(complexity, top_k);
     a.key_offset = h->key_offset;
-    a.out_keys = w->d_keys;
-    a.out_dists = w->d_dists;
-    a.out_counts = w->d_counts;
-    a.out_stats = w->d_stats;
+    a.out_keys = zero_copy ? reinterpret_cast<uint64_t *>(w->pin + o_keys) : w->d_keys;
+    a.out_dists = zero_copy ? reinterpret_cast<float *>(w->pin + o_dists) : w->d_dists;
+    a.out_counts = zero_copy ? reinterpret_cast<uint32_t *>(w->pin + o_counts) : w->d_counts;
+    a.out_stats = zero_copy ? reinterpret_cast<uint32_t *>(w->pin + o_stats) : w->d_stats;
     a.allow = flt ? flt->d_allow : (allow ? w->d_allow : nullptr);
     a.allow_stride = flt ? 0 : allow_stride;
     if (exact && flt) {
@@ -627,6 +645,16 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
     }
     if (rc) return fail(rc);
     std::vector<uint32_t> hstats(ns * nq * 4);
+    if (zero_copy) {
+        if (hipStreamSynchronize(st) != hipSuccess) {
+            leann_set_error("search: device error: %s", hipGetErrorString(hipGetLastError()));
+            return fail(LEANN_ERR_DEVICE);
+        }
+        memcpy(keys, w->pin + o_keys, no * 8);
+        memcpy(dists, w->pin + o_dists, no * 4);
+        memcpy(counts, w->pin + o_counts, nq * 4);
+        memcpy(hstats.data(), w->pin + o_stats, nq * 16);
+    } else
     if (hipMemcpyAsync(keys, w->d_keys, no * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(dists, w->d_dists, no * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(counts, w->d_counts, nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||

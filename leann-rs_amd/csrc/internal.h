@@ -15,6 +15,11 @@ struct Workspace { // staging of the host-pointer API; one per concurrent caller
     uint32_t *d_counts = nullptr, *d_stats = nullptr;
     uint8_t *d_allow = nullptr; // filtered searches: staged allow-bitmap(s)
     size_t cap_q = 0, cap_keys = 0, cap_dists = 0, cap_counts = 0, cap_stats = 0, cap_allow = 0;
+    // small calls (a single query is the reference's own call, traits.rs:16-21): one block of pinned, device-mapped host memory
+    // {queries | keys | dists | counts | stats}: the kernels read the queries from it and write the results into it, so the call
+    // is kernel launches + one stream synchronisation, with no copy engine in between
+    unsigned char *pin = nullptr;
+    size_t cap_pin = 0;
     hipStream_t stream = nullptr;
 };
 
