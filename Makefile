@@ -11,7 +11,7 @@ HDRS     := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) include/leann_back
 HOST     := leann-rs_amd/host
 CXXFLAGS := -O2 -std=c++17 -ffp-contract=off -Wall -Wextra -Wno-unused-parameter
 
-all: $(CSRC)/libleann_hip.so oracle $(HOST)/leann $(HOST)/host_selftest $(HOST)/host_selftest_asan
+all: $(CSRC)/libleann_hip.so oracle $(HOST)/leann $(HOST)/host_selftest $(HOST)/host_selftest_asan $(HOST)/serve_bench
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -26,6 +26,10 @@ $(HOST)/leann: $(HOST)/leann_cli.cpp $(HOST)/leann_host.hpp $(HOST)/json.hpp inc
 $(HOST)/host_selftest: $(HOST)/host_selftest.cpp $(HOST)/leann_host.hpp $(HOST)/json.hpp include/leann_backend.h $(CSRC)/libleann_hip.so
 	g++ $(CXXFLAGS) -o $@ $(HOST)/host_selftest.cpp -L$(CSRC) -lleann_hip -Wl,-rpath,'$$ORIGIN/../csrc' -Wl,-rpath,/opt/rocm/lib
 
+# the reference server's call pattern (many threads, one query per call) without the HTTP layer
+$(HOST)/serve_bench: $(HOST)/serve_bench.cpp include/leann_backend.h $(CSRC)/libleann_hip.so
+	g++ $(CXXFLAGS) -pthread -o $@ $(HOST)/serve_bench.cpp -L$(CSRC) -lleann_hip -Wl,-rpath,'$$ORIGIN/../csrc' -Wl,-rpath,/opt/rocm/lib
+
 # the host C++ (JSON parser, passage store, BM25, filters, search_with_options assembly) under AddressSanitizer + UBSan — CPU only
 # (GPU sanitizers are not available on this pool); tests/test_cpu_host.py runs it over the same fixtures as the plain build
 $(HOST)/host_selftest_asan: $(HOST)/host_selftest.cpp $(HOST)/leann_host.hpp $(HOST)/json.hpp include/leann_backend.h $(CSRC)/libleann_hip.so
@@ -36,7 +40,7 @@ oracle:
 	$(MAKE) -s -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o $(CSRC)/*.so $(HOST)/leann $(HOST)/host_selftest $(HOST)/host_selftest_asan
+	rm -f $(CSRC)/*.o $(CSRC)/*.so $(HOST)/leann $(HOST)/host_selftest $(HOST)/host_selftest_asan $(HOST)/serve_bench
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -748,7 +748,7 @@ def main():
                 t0 = time.perf_counter()
                 chk(fn(hnd, Ql[i].ctypes.data_as(f32p), k, ef, kb.ctypes.data_as(u64p), db.ctypes.data_as(f32p), C.byref(nb)))
                 ts[i] = time.perf_counter() - t0
-            lat = {"call": "leann_backend_search (host pointers, 1 query, H2D + kernel + D2H + sync)", "n": int(nlat), "ef": ef, "top_k": k,
+            lat = {"call": "leann_backend_search (host pointers, 1 query: staged in a pinned device-mapped block, kernel, sync)", "n": int(nlat), "ef": ef, "top_k": k,
                    "p50_ms": float(np.percentile(ts, 50) * 1e3), "p99_ms": float(np.percentile(ts, 99) * 1e3), "mean_ms": float(ts.mean() * 1e3)}
 
             def callers(nthreads, per):
@@ -763,15 +763,20 @@ def main():
                 [t.join() for t in th]
                 return nthreads * per / (time.perf_counter() - t0)
             callers(64, 5)
-            lat["callers64_qps_plain"] = callers(64, 40)
+            lat["callers64_qps_auto"] = callers(64, 40)      # the handle as opened: concurrent callers coalesce by themselves
+            searcher.set_coalescing(0, 0)
+            callers(64, 5)
+            lat["callers64_qps_plain"] = callers(64, 40)     # coalescing switched off: one launch per caller
             searcher.set_coalescing(100, 64)
             callers(64, 5)
             lat["callers64_qps_coalesced"] = callers(64, 40)
-            lat["coalescing"] = "leann_backend_set_coalescing(wait_us=100, max_batch=64)"
+            lat["coalescing"] = ("auto = default handle (dispatcher installed when a caller finds another in flight: 50 us, 64 queries); plain = "
+                                 "leann_backend_set_coalescing(0, 0); coalesced = leann_backend_set_coalescing(wait_us=100, max_batch=64). "
+                                 "Python caller threads (GIL hand-over per wake-up): leann-rs_amd/host/serve_bench measures the same natively")
             searcher.set_coalescing(0, 0)
             out["single_query"] = lat
-            log(f"single query: p50 {lat['p50_ms']:.3f} ms, p99 {lat['p99_ms']:.3f} ms; 64 callers: {lat['callers64_qps_plain']:.0f} q/s plain, "
-                f"{lat['callers64_qps_coalesced']:.0f} q/s coalesced")
+            log(f"single query: p50 {lat['p50_ms']:.3f} ms, p99 {lat['p99_ms']:.3f} ms; 64 callers: {lat['callers64_qps_auto']:.0f} q/s as opened, "
+                f"{lat['callers64_qps_plain']:.0f} q/s plain, {lat['callers64_qps_coalesced']:.0f} q/s coalesced")
         except Exception as e:  # noqa: BLE001
             log("single-query timing failed:", e)
 

@@ -759,28 +759,56 @@ struct Coalescer {
 // Safe against searches in flight: the handle's coalescer is swapped out under h->mu, the lock is RELEASED, and only then is the old
 // dispatcher stopped and joined (it drains its queue first; its launches take h->mu themselves).  Callers hold a shared_ptr, so the
 // object outlives every waiter; a caller that arrives after `stop` answers its query directly.
+static std::shared_ptr<Coalescer> make_coalescer(leann_backend *h, uint32_t wait_us, uint32_t max_batch) {
+    auto fresh = std::make_shared<Coalescer>();
+    fresh->h = h;
+    fresh->wait_us = wait_us;
+    fresh->max_batch = max_batch ? max_batch : 4096;
+    Coalescer *c = fresh.get();
+    fresh->th = std::thread([c] { c->run(); });
+    return fresh;
+}
+static void retire_coalescer(std::shared_ptr<Coalescer> old) {
+    if (!old) return;
+    { std::lock_guard<std::mutex> l2(old->mu); old->stop = true; }
+    old->cv_submit.notify_all();
+    old->th.join();
+}
 extern "C" int leann_backend_set_coalescing(leann_backend *h, uint32_t wait_us, uint32_t max_batch) {
     if (!h) { leann_set_error("leann_backend_set_coalescing: null handle"); return LEANN_ERR_INVALID; }
     std::shared_ptr<Coalescer> fresh, old;
-    if (!(wait_us == 0 && max_batch == 0)) {
-        fresh = std::make_shared<Coalescer>();
-        fresh->h = h;
-        fresh->wait_us = wait_us;
-        fresh->max_batch = max_batch ? max_batch : 4096;
-        Coalescer *c = fresh.get();
-        fresh->th = std::thread([c] { c->run(); });
-    }
+    const bool off = wait_us == 0 && max_batch == 0;
+    if (!off) fresh = make_coalescer(h, wait_us, max_batch);
     {
         std::lock_guard<std::mutex> lk(h->mu);
         old.swap(h->coalescer);
         h->coalescer = fresh;
+        h->coalesce_mode = off ? 2 : 1;
     }
-    if (old) {
-        { std::lock_guard<std::mutex> l2(old->mu); old->stop = true; }
-        old->cv_submit.notify_all();
-        old->th.join();
-    }
+    retire_coalescer(old);
     return LEANN_OK;
+}
+// Automatic mode (the default; LEANN_COALESCE=off in the environment or leann_backend_set_coalescing(h, 0, 0) switch it off): the
+// reference's server calls search from many threads without knowing about batches (cli/serve.rs:289-292).  The first caller that
+// finds another single-query call in flight on the handle installs a dispatcher (50 us window, 64 queries) and queues behind it; a
+// caller that is alone is answered directly, at the latency of one launch.
+static std::shared_ptr<Coalescer> auto_coalescer(leann_backend *h) {
+    static const bool enabled = [] { const char *e = getenv("LEANN_COALESCE"); return !(e && (!strcmp(e, "off") || !strcmp(e, "0"))); }();
+    if (!enabled) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (h->coalesce_mode != 0) return h->coalescer;
+        if (h->coalescer) return h->coalescer;
+    }
+    std::shared_ptr<Coalescer> fresh = make_coalescer(h, 50, 64), lost;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (h->coalesce_mode == 0 && !h->coalescer) { h->coalescer = fresh; return fresh; }
+        lost = fresh; // somebody else installed one (or configured the handle) meanwhile
+        fresh = h->coalescer;
+    }
+    retire_coalescer(lost);
+    return fresh;
 }
 extern "C" int leann_backend_coalescing_stats(const leann_backend *hc, uint64_t *n_launches, uint64_t *n_queries) {
     leann_backend *h = const_cast<leann_backend *>(hc);
@@ -798,7 +826,17 @@ extern "C" int leann_backend_search(const leann_backend *hc, const float *query,
     if (!n_out) { leann_set_error("leann_backend_search: n_out is null"); return LEANN_ERR_INVALID; }
     leann_backend *h = const_cast<leann_backend *>(hc);
     std::shared_ptr<Coalescer> c;
-    if (h && query && keys && dists && top_k > 0 && h->g.n > 0) { std::lock_guard<std::mutex> lk(h->mu); c = h->coalescer; }
+    struct InFlight { // single-query calls on this handle right now (automatic coalescing)
+        std::atomic<int> *a;
+        int before;
+        explicit InFlight(std::atomic<int> *p) : a(p), before(p ? p->fetch_add(1) : 0) {}
+        ~InFlight() { if (a) a->fetch_sub(1); }
+    } inflight(h ? &h->singles_in_flight : nullptr);
+    if (h && query && keys && dists && top_k > 0 && h->g.n > 0) {
+        int mode;
+        { std::lock_guard<std::mutex> lk(h->mu); c = h->coalescer; mode = h->coalesce_mode; }
+        if (!c && mode == 0 && inflight.before > 0) c = auto_coalescer(h);
+    }
     if (c) {
         PendingQuery p{query, top_k, complexity, keys, dists, n_out};
         std::unique_lock<std::mutex> lk(c->mu);

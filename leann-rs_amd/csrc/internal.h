@@ -2,6 +2,7 @@
 #pragma once
 #include "search.cuh"
 #include "../../include/leann_backend.h"
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -47,6 +48,10 @@ struct leann_backend {
     float *Wf32 = nullptr;
     std::map<hipStream_t, std::pair<float *, size_t>> proj_scratch;
     std::shared_ptr<Coalescer> coalescer; // optional request coalescing for single-query callers (api.hip); swapped under `mu`
+    // 0 = automatic (default): a leann_backend_search caller that finds another one in flight goes through a dispatcher created on the
+    // spot, a lone caller is answered directly; 1 = configured by leann_backend_set_coalescing; 2 = switched off by it
+    int coalesce_mode = 0;
+    std::atomic<int> singles_in_flight{0};
 };
 
 // LEANN_LOG=error|warn|info|debug (default warn) -> stderr, "LEVEL leann_hip: message" (the reference logs through tracing, cli/mod.rs:38-43)

@@ -205,9 +205,22 @@ def test_request_coalescing_for_single_query_callers(la, po, gpu):
         [t.join() for t in th]
         return time.perf_counter() - t0
 
+    # the handle as opened: a lone caller is answered directly (no dispatcher exists yet) ...
+    assert (s.search(Q[3], 10, 64)[0] == ref_k[3]).all()
+    with pytest.raises(la.LeannError):
+        s.coalescing_stats()
+    # ... concurrent callers install one by themselves (automatic mode) and are answered in batches, same results
+    t_auto = run()
+    for i in range(len(Q)):
+        assert (out[i][0] == ref_k[i]).all() and (out[i][1] == ref_d[i]).all()
+    st_auto = s.coalescing_stats()
+    assert 0 < st_auto["queries"] <= len(Q) and st_auto["launches"] < st_auto["queries"]
+    s.set_coalescing(0, 0)  # switched off: one launch per caller
     t_plain = run()
     for i in range(len(Q)):
         assert (out[i][0] == ref_k[i]).all() and (out[i][1] == ref_d[i]).all()
+    with pytest.raises(la.LeannError):
+        s.coalescing_stats()
     s.set_coalescing(300, 1024)
     t_coal = run()
     for i in range(len(Q)):
@@ -225,7 +238,8 @@ def test_request_coalescing_for_single_query_callers(la, po, gpu):
         assert (r1[i][0] == k5[i]).all() and (r2[i][0] == ref_k[i]).all()
     s.set_coalescing(0, 0)
     assert (s.search(Q[3], 10, 64)[0] == ref_k[3]).all()
-    print(f"single-query callers: plain {len(Q)/t_plain:.0f} q/s, coalesced {len(Q)/t_coal:.0f} q/s, launches {st['launches']}")
+    print(f"single-query callers: as opened {len(Q)/t_auto:.0f} q/s ({st_auto['launches']} launches for {st_auto['queries']} queued queries), "
+          f"plain {len(Q)/t_plain:.0f} q/s, coalesced {len(Q)/t_coal:.0f} q/s, launches {st['launches']}")
     s.close()
 
 
