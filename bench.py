@@ -17,7 +17,9 @@ N > 1 (launched by torch.distributed.run, one rank per GPU):
                value = batch * K / t: END-TO-END queries/s over the whole N x rows corpus (every query
                is answered once, by all shards together).  Weak scaling therefore means: the corpus
                grows N-fold at (ideally) constant queries/s.  The per-shard search rate N * batch * K / t
-               rides along as "shard_searches_per_s".
+               rides along as "shard_searches_per_s", and a second barrier-bracketed region of the same K steps WITHOUT the
+               collective — every rank answering different query batches from its own index, i.e. N replicas of a `rows`-row
+               corpus ("report both shard and replica curves") — as "replica_mode".
   mode replica every rank holds the whole `rows`-vector index and takes different query batches;
                no data-path collective.
 """
@@ -620,6 +622,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- N > 1, second curve ("report both shard and replica curves"): no collective — every rank answers DIFFERENT
+    # query batches from its own `rows`-row index, which is what N replicas of a `rows`-row corpus do.  Not `value`: a side key.
+    replica_qps = None
+    if shard and allow is None:
+        def local(step):
+            qb = (step + 3 * rank) % n_pool
+            searcher.search_batch_device(Q.data_ptr() + qb * B * ld * 4, B, k, ef, kbuf[0].data_ptr(), dbuf[0].data_ptr(), cbuf[0].data_ptr(), None, sp)
+        for w in range(args.warmup):
+            local(w)
+        stream.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_ in range(args.steps):
+            local(s_)
+        stream.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        replica_qps = B * args.steps * world / float(t2.item())
+
     # ---- roofline of the dominant kernel (beam_search_kernel): algorithmic bytes / HIP-event time --
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     kern_avg_s = float(np.mean(kern_ms)) * 1e-3
@@ -709,6 +733,10 @@ def main():
                            "kernel": "score_mfma_kernel<true> (+ compaction, fold, finalize inside the HIP-event bracket)",
                            "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_flops_per_launch": flops, "allowed_rows": n_allowed}
     if shard:
+        if replica_qps is not None:
+            out["replica_mode"] = {"value": replica_qps, "unit": "queries/s",
+                                   "note": f"no collective: each of the {world} ranks answers its own query batches from its own {rows}-row index "
+                                           f"(N replicas of a {rows}-row corpus); same K steps, barrier-bracketed, max over ranks"}
         out["shard_searches_per_s"] = B * args.steps * world / elapsed
         out["config"]["value_unit_note"] = (f"value = end-to-end queries/s over the {corpus_total}-row corpus (every query searched on all "
                                             f"{world} shards, lists all-gathered over {'RCCL inside the library' if rccl else dist.get_backend()}, merged on every rank); "
