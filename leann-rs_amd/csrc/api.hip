@@ -320,7 +320,11 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
         }
     }
     if (a.ef < a.k) a.ef = a.k; // diskann.rs:54
-    a.hash_bits = pick_hash_bits(a.ef);
+    // Rows of up to 512 floats leave registers for 5-7 workgroups per CU where the 32 KiB visited table allows 4, and rows this short
+    // do not hide a hop's dependent phases behind their own transfer: narrow beams take the 16 KiB table (the heaviest queries
+    // move to the HBM pool).  10M rows, ef = 64: 128-d 2.41 -> 3.10 M queries/s, 256-d 2.16 -> 2.72 M, 384-d 1.66 -> 1.85 M, 512-d
+    // unchanged; 768-d and wider are bound by HBM either way and keep the larger table (scripts/exp/dims_sweep.py).
+    a.hash_bits = (h->g.ld <= 512 && a.ef <= 64 && !a.q_rows && !getenv("LEANN_DEBUG_HASH_BITS")) ? 12u : pick_hash_bits(a.ef);
     int rc = ensure_gpool(h);
     if (rc) return rc;
     set_pool_args(h, a);
