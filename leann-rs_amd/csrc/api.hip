@@ -337,8 +337,10 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
         case 4: return launch_search_T<4, 3>(g, a, st);
         case 5: case 6: return launch_search_T<6, 2>(g, a, st);
         case 7: case 8: return launch_search_T<8, 2>(g, a, st);
+        case 9: case 10: case 11: case 12: return launch_search_T<12, 1>(g, a, st); // 3 072-d: text-embedding-3-large (embedding/models.rs:113)
+        case 13: case 14: case 15: case 16: return launch_search_T<16, 1>(g, a, st);
         default:
-            leann_set_error("search: dims %u > 2048 not supported", g.d);
+            leann_set_error("search: dims %u > 4096 not supported", g.d);
             return LEANN_ERR_INVALID;
     }
 }
@@ -907,7 +909,7 @@ int leann_internal_from_host(int backend, size_t n, size_t dims, uint32_t M, uin
                              size_t n_upper_lists, const float *vectors, const unsigned char *feat_rows, uint32_t feat_h, uint32_t row_bytes,
                              const float *Wf32, int device, uint64_t key_offset, leann_backend **out) {
     const bool feat = feat_rows != nullptr;
-    if (!out || dims == 0 || dims > 2048 || n >= (1ull << 31) || (n && ((!vectors && !feat) || !adj0 || !upper_off)) ||
+    if (!out || dims == 0 || dims > 4096 || n >= (1ull << 31) || (n && ((!vectors && !feat) || !adj0 || !upper_off)) ||
         (backend != LEANN_BACKEND_HNSW && backend != LEANN_BACKEND_DISKANN) ||
         (feat && (!Wf32 || feat_h == 0 || (feat_h & 3) || feat_h > 1024 || row_bytes < 2 * feat_h + 4 || (row_bytes & 7)))) {
         leann_set_error("leann_backend_from_arrays: invalid arguments");

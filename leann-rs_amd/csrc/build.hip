@@ -715,7 +715,7 @@ static constexpr uint64_t LEVEL_SEED = 0x5EED0003ull;
 extern "C" int leann_backend_build_device(int backend, const float *d_vectors, size_t n, size_t dims, size_t ld,
                                           size_t graph_degree, size_t complexity, int device, uint64_t key_offset,
                                           int take_copy, leann_backend **out) {
-    if (!out || (n && !d_vectors) || dims == 0 || dims > 2048 || ld < dims || (ld & 3) || n >= (1ull << 31)) {
+    if (!out || (n && !d_vectors) || dims == 0 || dims > 4096 || ld < dims || (ld & 3) || n >= (1ull << 31)) {
         leann_set_error("leann_backend_build_device: invalid arguments (n=%zu dims=%zu ld=%zu)", n, dims, ld);
         return LEANN_ERR_INVALID;
     }

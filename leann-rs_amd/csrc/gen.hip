@@ -99,7 +99,7 @@ static int launch_gen(uint64_t seed, uint32_t d, uint32_t ld, uint32_t r, uint32
 extern "C" int leann_synth_rows_device(uint64_t seed, uint32_t dims, uint32_t ld, uint32_t r, uint32_t n_clusters,
                                        float sigma, uint32_t stream_id, uint64_t i0, uint64_t n, float *d_out,
                                        void *stream) {
-    if (!d_out || dims == 0 || ld < dims || (ld & 3) || ld > 2048 || r > 256 || (r && n_clusters == 0)) {
+    if (!d_out || dims == 0 || ld < dims || (ld & 3) || ld > 4096 || r > 256 || (r && n_clusters == 0)) {
         leann_set_error("leann_synth_rows_device: invalid arguments (dims=%u ld=%u r=%u)", dims, ld, r);
         return LEANN_ERR_INVALID;
     }
@@ -134,7 +134,9 @@ extern "C" int leann_synth_rows_device(uint64_t seed, uint32_t dims, uint32_t ld
         case 3: rc = launch_gen<3>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
         case 4: rc = launch_gen<4>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
         case 5: case 6: rc = launch_gen<6>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
-        default: rc = launch_gen<8>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
+        case 7: case 8: rc = launch_gen<8>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
+        case 9: case 10: case 11: case 12: rc = launch_gen<12>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
+        default: rc = launch_gen<16>(seed, dims, ld, r, n_clusters, sigma, stream_id, i0, n, P, d_out, st); break;
     }
     return rc;
 }

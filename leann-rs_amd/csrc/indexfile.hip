@@ -173,7 +173,7 @@ static int load_own_file(const std::string &path, int backend, size_t dims, int 
     if (hd.version != 1 && hd.version != 2) return bad("unsupported version");
     if (hd.kind != (uint32_t)backend) return bad(backend == LEANN_BACKEND_HNSW ? "the file holds a DiskANN graph, an HNSW index was asked for"
                                                                                  : "the file holds an HNSW graph, a DiskANN index was asked for");
-    if (hd.d == 0 || hd.d > 2048 || hd.M == 0 || hd.M > 64 || hd.M0 == 0 || hd.M0 > 64 || hd.n >= (1ull << 31) || hd.max_level > 15 ||
+    if (hd.d == 0 || hd.d > 4096 || hd.M == 0 || hd.M > 64 || hd.M0 == 0 || hd.M0 > 64 || hd.n >= (1ull << 31) || hd.max_level > 15 ||
         hd.n_upper_lists > hd.n * 15ull || (hd.n && hd.entry >= hd.n))
         return bad("header fields out of range");
     if (hd.version == 2 && (hd.feat_h == 0 || (hd.feat_h & 3) || hd.feat_h > 1024 || hd.row_bytes < 2 * hd.feat_h + 4 || (hd.row_bytes & 7) ||

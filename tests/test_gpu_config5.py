@@ -60,6 +60,35 @@ def test_vamana_r64_d1536_matches_oracle(la, po, gpu):
     s.close()
 
 
+@pytest.mark.parametrize("backend,d", [("hnsw", 3072), ("diskann", 3072), ("hnsw", 4096)])
+def test_wide_embeddings_built_saved_reopened(la, po, gpu, tmp_path, backend, d):
+    """3 072-d is text-embedding-3-large (src/embedding/models.rs:113): the T = 12 instantiation of the traversal kernel (4 096: T = 16),
+    through the whole boundary — built on the GPU, saved, reopened with load_searcher's arguments, walked by the GPU and by the oracle."""
+    n = 6000
+    bt = la.BackendType.Hnsw if backend == "hnsw" else la.BackendType.DiskAnn
+    dX = _device_rows(la, n, d, 0)
+    Q = _device_rows(la, 64, d, 1).to_host()
+    X = dX.to_host()
+    stem = str(tmp_path / "documents.leann")
+    la.BackendBuilder(bt).build(X, [], stem, d, 16, 64)
+    s = la.BackendSearcher.load(bt, stem, d)
+    g = s.graph_export()
+    M0 = g["M0"]
+    G = po.Graph.from_arrays(X, g["M"], M0, g["max_level"], g["entry"], g["levels"], g["upper_off"], g["adj0"], g["adjU"])
+    algo = 0 if backend == "hnsw" else 1
+    for k, ef in ((10, 64), (1, 1), (5, 20)):
+        ok, od, oc, ost = G.search_batch(Q, k, ef, algo, nthreads=8)
+        s.stats(reset=True)
+        gk, gd, gc = s.search_batch(Q, k, ef)
+        assert (gc == oc).all() and (gk == ok).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+        assert s.stats()["n_dist_evals"] == int(ost[:, 0].sum())
+    gk, _, _ = s.search_batch(Q, 10, 64)
+    assert recall_at_k(gk, po.exact_topk(X, Q, 10)) >= 0.95
+    k1, d1 = s.search(Q[7], 10, 64)  # single-query trait call: 16 waves per query
+    assert (k1 == gk[7]).all()
+    s.close()
+
+
 # ---- (ii) DiskANN + hybrid through IndexSearcher ------------------------------------------------------------------------
 FX = json.load(open(os.path.join(ROOT, "tests", "golden", "searcher_cases.json")))
 DIMS = 1536

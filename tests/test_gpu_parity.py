@@ -29,7 +29,7 @@ def _assert_same(po, G, s, Q, k, ef, algo=0):
     return gk
 
 
-@pytest.mark.parametrize("d,r", [(128, 0), (128, 32), (768, 64), (1536, 64), (100, 16), (260, 8)])
+@pytest.mark.parametrize("d,r", [(128, 0), (128, 32), (768, 64), (1536, 64), (100, 16), (260, 8), (3072, 64), (4096, 16)])
 def test_synth_rows_bit_exact(la, po, gpu, d, r):
     n = 300
     ld = (d + 3) // 4 * 4
@@ -43,7 +43,8 @@ def test_synth_rows_bit_exact(la, po, gpu, d, r):
         assert (got[:, d:] == 0).all()
 
 
-@pytest.mark.parametrize("n,d,M,ef", [(3000, 128, 16, 64), (2000, 768, 32, 128), (1500, 1536, 8, 32), (800, 100, 4, 10)])
+@pytest.mark.parametrize("n,d,M,ef", [(3000, 128, 16, 64), (2000, 768, 32, 128), (1500, 1536, 8, 32), (800, 100, 4, 10),
+                                      (1200, 3072, 8, 48), (700, 4096, 8, 32), (900, 2500, 8, 40)])  # 3 072: text-embedding-3-large (embedding/models.rs:113)
 def test_hnsw_search_matches_oracle(la, po, gpu, n, d, M, ef):
     X = synth(po, n, d)
     Q = synth(po, 64, d, stream=1)
