@@ -1007,8 +1007,17 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
 
 // One workgroup per query.  BUILD only names the instantiation used by index construction (queries are
 // base rows, k = ef) so that profiles keep query launches and construction launches apart.
+// Narrow rows (<= 512 floats) are short of workgroups per CU, not of HBM (api.hip gives them the 16 KiB visited table): the compiler is
+// asked for 6 workgroups per CU at 257..512 floats (80 registers instead of 83, no spill; 384-d 1.84 -> 1.95 M queries/s) and for 8 at
+// <= 256 floats (64 registers, one spilled; 128-d 3.10 -> 3.64 M, 256-d 2.67 -> 2.80 M; scripts/exp/dims_sweep.py through scripts/variant.sh).
+#ifndef LEANN_T2_OCC
+#define LEANN_T2_OCC 6
+#endif
+#ifndef LEANN_T1_OCC
+#define LEANN_T1_OCC 8
+#endif
 template <int T, int R, int NW, bool BUILD>
-__global__ void __launch_bounds__(NW * 64) beam_search_kernel(GraphView g, SearchArgs a) {
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && T == 2) ? LEANN_T2_OCC : (NW == 4 && T == 1) ? LEANN_T1_OCC : 1) beam_search_kernel(GraphView g, SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t qi = blockIdx.x;
     if (qi >= a.nq) return;
