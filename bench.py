@@ -588,7 +588,7 @@ def main():
     # recall that goes into the record is measured on the OTHER half (disjoint queries: no tuning on the reported set)
     half = nrq // 2 if ef_auto and nrq >= 200 else 0
     if ef_auto and not (allow is not None and args.filter_exact):
-        for cand in (40, 44, 48, 52, 56, 60, 64, 72, 80, 96, 112, 128):
+        for cand in (40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 88, 96, 104, 112, 120, 128):
             ef = cand
             if measure_recall(0, half or nrq) >= 0.955:
                 break
