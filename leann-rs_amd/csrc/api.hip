@@ -247,7 +247,7 @@ static int launch_search_NW(const GraphView &g, const SearchArgs &a, hipStream_t
 // all ~40 new rows of a hop are then in flight at once (results are identical: same order, same sums).
 template <int T, int R>
 static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t st) {
-    int nw = a.nq <= 512 ? 16 : 4;
+    int nw = a.nq <= 384 ? 16 : a.nq <= 640 ? 8 : 4; // 10M x 768, ef = 56: 16 waves win up to 256 queries, 8 at 512, 4 from 768 on (scripts/exp/batch_sweep.py)
     if (const char *e = getenv("LEANN_DEBUG_NW")) nw = atoi(e);
     if (nw >= 16) return launch_search_NW<T, R, 16>(g, a, st);
     if (nw >= 8) return launch_search_NW<T, R, 8>(g, a, st);
