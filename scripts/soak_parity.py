@@ -11,8 +11,8 @@ n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
 bad = 0
 for c in range(n_cfg):
-    n = int(rng.integers(50, 6000)); d = int(rng.choice([16, 64, 100, 128, 260, 768, 1000, 1536])); M = int(rng.choice([2, 4, 8, 16, 32]))
-    ef = int(rng.integers(1, 300)); k = int(rng.integers(1, min(ef, 64) + 1)); nq = int(rng.choice([1, 7, 64, 600]))
+    n = int(rng.integers(50, 6000)); d = int(rng.choice([16, 64, 100, 128, 260, 384, 768, 1000, 1536, 2500, 3072, 4096])); M = int(rng.choice([2, 4, 8, 16, 32]))
+    ef = int(rng.integers(1, 300)); k = int(rng.integers(1, min(ef, 64) + 1)); nq = int(rng.choice([1, 7, 64, 400, 600, 700]))
     r = int(rng.choice([0, 8, 64])); vam = bool(rng.integers(0, 2))
     X = po.gen_rows(0x5EED0001 + c, d, min(r, d), 97, 0.8, 0, 0, n)
     Q = po.gen_rows(0x5EED0001 + c, d, min(r, d), 97, 0.8, 1, 0, nq)
