@@ -27,6 +27,7 @@ extern "C" {
                           out: *mut *mut LeannBackend) -> c_int;
     fn leann_backend_search(h: *const LeannBackend, query: *const f32, top_k: usize, complexity: usize,
                             keys: *mut u64, dists: *mut f32, n_out: *mut usize) -> c_int;
+    #[allow(dead_code)]
     fn leann_backend_set_coalescing(h: *mut LeannBackend, wait_us: u32, max_batch: u32) -> c_int;
     fn leann_backend_len(h: *const LeannBackend) -> usize;
     fn leann_backend_close(h: *mut LeannBackend);
@@ -58,8 +59,8 @@ impl GpuSearcher {
         if rc != 0 {
             return Err(last_error());
         }
-        // a server calls search() from many tokio workers (cli/serve.rs:289-292): let the library batch concurrent callers
-        unsafe { leann_backend_set_coalescing(h, 100, 1024) };
+        // a server calls search() from many tokio workers (cli/serve.rs:289-292): the library batches concurrent callers by itself
+        // (a lone caller — `leann search` — is answered directly); leann_backend_set_coalescing(h, wait_us, max_batch) only tunes that
         Ok(Self { h })
     }
 }
