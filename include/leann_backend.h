@@ -114,7 +114,8 @@ int leann_backend_search_filter_batch(const leann_backend *h, const float *queri
  * call, src/cli/serve.rs:289-292).  Concurrent callers are gathered for up to wait_us microseconds (or
  * max_batch queries) and answered by one batched launch; results are identical.  (0, 0) disables.
  * Without this call a handle coalesces automatically: a leann_backend_search caller that finds another one in
- * flight queues behind a dispatcher (50 us, 64 queries) created at that moment, a lone caller is answered
+ * flight queues behind a dispatcher (50 us or 64 queries, ending early once the callers of the previous round
+ * are all waiting again) created at that moment, a lone caller is answered
  * directly.  LEANN_COALESCE=off in the environment switches the automatic mode off for the process. */
 int leann_backend_set_coalescing(leann_backend *h, uint32_t wait_us, uint32_t max_batch);
 int leann_backend_coalescing_stats(const leann_backend *h, uint64_t *n_launches, uint64_t *n_queries);

@@ -32,7 +32,8 @@ int main(int argc, char **argv) {
     CHECK(leann_backend_build_device(LEANN_BACKEND_HNSW, dX, n, d, d, 32, 128, 0, 0, 0, &h));
     fprintf(stderr, "index: %zu x %zu, built in %.1f s\n", n, d, std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count());
     for (int mode = 0; mode < 3; mode++) { // 0: the handle as opened (automatic coalescing), 1: switched off, 2: configured
-        if (mode) CHECK(leann_backend_set_coalescing(h, mode == 2 ? 100 : 0, mode == 2 ? 64 : 0));
+        const uint32_t wait_us = getenv("SERVE_WAIT_US") ? (uint32_t)atoi(getenv("SERVE_WAIT_US")) : 100, max_b = getenv("SERVE_MAX_BATCH") ? (uint32_t)atoi(getenv("SERVE_MAX_BATCH")) : 64;
+        if (mode) CHECK(leann_backend_set_coalescing(h, mode == 2 ? wait_us : 0, mode == 2 ? max_b : 0));
         std::vector<std::vector<double>> lat(T);
         std::atomic<int> failed{0};
         auto worker = [&](int t, int ncalls, bool record) {
@@ -54,7 +55,7 @@ int main(int argc, char **argv) {
         for (auto &v : lat) all.insert(all.end(), v.begin(), v.end());
         std::sort(all.begin(), all.end());
         printf("{\"threads\": %d, \"coalescing\": %s, \"queries_per_s\": %.0f, \"p50_us\": %.1f, \"p99_us\": %.1f, \"failed\": %d, \"rows\": %zu, \"dims\": %zu, \"ef\": %zu}\n",
-               T, mode == 0 ? "\"automatic (default)\"" : mode == 2 ? "\"wait 100 us, max 64\"" : "\"off\"", (double)T * calls / secs, all[all.size() / 2], all[(size_t)(all.size() * 0.99)], failed.load(), n, d, ef);
+               T, mode == 0 ? "\"automatic (default)\"" : mode == 2 ? "\"configured (SERVE_WAIT_US / SERVE_MAX_BATCH, default 100 us / 64)\"" : "\"off\"", (double)T * calls / secs, all[all.size() / 2], all[(size_t)(all.size() * 0.99)], failed.load(), n, d, ef);
     }
     leann_backend_close(h);
     leann_device_free(dX);
