@@ -44,9 +44,11 @@ WORKLOADS = {
     "hnsw1m": dict(rows=1_000_000, d=768, M=32, efc=128, ef=128),     # BASELINE configs[1]
     "hnsw100m_shard8": dict(rows=12_500_000, d=768, M=32, efc=200, ef=128),  # BASELINE configs[3]: 100M x 768 = 8 shards of 12.5M (--gpus 8)
     "hnsw100k": dict(rows=100_000, d=768, M=32, efc=128, ef=128),     # quick check
-    # configs[4] search leg: DiskANN/Vamana, 1536-d.  R = 64 (R = 32 reaches recall 0.98 at 1M but only 0.81 at 5M)
+    # configs[4] search leg: DiskANN/Vamana, 1536-d.  R = 64 (R = 32 reaches recall 0.98 at 1M but only 0.60 at 10M with beam 128; 0.81 with a
+    # second build pass, LEANN_VAMANA_PASSES=2: profiles/r02_vamana10m1536_r32_bench.json)
     "vamana10m1536": dict(rows=10_000_000, d=1536, M=64, efc=128, ef=128, backend=1),
     "vamana1m1536": dict(rows=1_000_000, d=1536, M=64, efc=128, ef=128, backend=1),
+    "vamana10m1536_r32": dict(rows=10_000_000, d=1536, M=32, efc=128, ef=128, backend=1),  # configs[4]'s other degree (max_degree = 32, beam 128)
     # configs[2]: recompute-on (no stored vectors), batch-64 queries: features [rows x 256] bf16 + W [256 x 768] bf16
     "recompute10m": dict(rows=10_000_000, d=768, h=256, kind="recompute", batch=64),
     "recompute1m": dict(rows=1_000_000, d=768, h=256, kind="recompute", batch=64),

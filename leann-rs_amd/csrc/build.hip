@@ -190,7 +190,24 @@ __global__ void __launch_bounds__(256) select_kernel(const float *__restrict__ X
         c_id[i] = i < nc ? (uint32_t)cand_keys[(size_t)qi * efc + i] : 0u;
         c_d[i] = i < nc ? cand_d[(size_t)qi * efc + i] : 0.f;
     }
+    if (threadIdx.x == 0) s_cnt = NCMAX;
     __syncthreads();
+    // a point that is already linked (second Vamana pass) finds itself: drop it from its own candidates
+    for (uint32_t i = threadIdx.x; i < nc; i += 256)
+        if (c_id[i] == q) s_cnt = i;
+    __syncthreads();
+    if (s_cnt < nc) {
+        const uint32_t self = s_cnt;
+        uint32_t mv_id[NCMAX / 256 + 1];
+        float mv_d[NCMAX / 256 + 1];
+        int t = 0;
+        for (uint32_t i = self + threadIdx.x; i + 1 < nc; i += 256, t++) { mv_id[t] = c_id[i + 1]; mv_d[t] = c_d[i + 1]; }
+        __syncthreads();
+        t = 0;
+        for (uint32_t i = self + threadIdx.x; i + 1 < nc; i += 256, t++) { c_id[i] = mv_id[t]; c_d[i] = mv_d[t]; }
+        nc--;
+        __syncthreads();
+    }
     if (exp_keys && nc > 0) {
         // Vamana: prune over the visited set V = final beam  ∪  nodes expanded on the way from the medoid
         // (DiskANN Alg. 2/3).  Path nodes are the expanded entries farther than the beam's worst entry; they
@@ -245,6 +262,7 @@ __global__ void __launch_bounds__(256) select_kernel(const float *__restrict__ X
         prop_key[(size_t)qi * msel + j] = pk; // (target, dist) ; padding sorts to the end
         prop_src[(size_t)qi * msel + j] = q;
     }
+    for (uint32_t j = ns + threadIdx.x; j < cap; j += 256) ids[j] = LEANN_EMPTY; // (a re-linked point: nothing of its old list stays behind the new one)
 }
 
 // heads of equal-target runs in the sorted proposal array
@@ -491,7 +509,8 @@ static int builder_alloc_scratch(Builder &b, size_t bmax) {
 }
 
 // Insert order[s0 .. n) into the graph that already holds order[0 .. s0).
-static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_host_upper /* unused */, size_t s0, size_t n) {
+static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_host_upper /* unused */, size_t s0, size_t n,
+                                bool refine = false) {
     (void)order_host_upper;
     leann_backend *h = b.h;
     const uint32_t efc = h->efc;
@@ -504,7 +523,7 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
         // rule here — two thirds of a 50k-row index went in without seeing their batch mates and recall@10 at ef = 32 fell 1.6
         // points below the sequential builder's (tests/test_gpu_builder_quality.py); from ~130k rows on the cap is bmax anyway.
         static const size_t frac = [] { const char *e = getenv("LEANN_BUILD_BATCH_FRACTION"); int v = e ? atoi(e) : 8; return (size_t)(v >= 1 ? v : 8); }();
-        size_t B = std::min<size_t>(std::min<size_t>(b.bmax, std::max<size_t>(1, s / frac)), n - s);
+        size_t B = std::min<size_t>(std::min<size_t>(b.bmax, refine ? b.bmax : std::max<size_t>(1, s / frac)), n - s);
         const uint32_t Lmax = h->g.max_level;
         // ---- phase 1: searches (graph does not contain any point of the batch yet) ----------------
         struct LevelJob { uint32_t level, nq; size_t off; };
@@ -673,6 +692,13 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
     size_t bmax = bmax_hint ? bmax_hint : 16384;
     rc = builder_alloc_scratch(b, bmax);
     if (rc == LEANN_OK) rc = builder_insert_range(b, {}, s0, n);
+    // DiskANN builds in two passes over the points (the second one re-links every point against the finished graph).  Optional here
+    // (LEANN_VAMANA_PASSES=2), off by default — 10M x 1536: at R = 64 it doubles the build (82 -> 173 s) and buys nothing (recall@10 0.95
+    // needs L = 76 instead of 72); at R = 32, where one pass is not enough for 10M clustered rows (recall 0.60 at L = 128), it lifts the
+    // recall to 0.81 — still not a usable index, which is why the 10M benchmarks use R = 64.
+    static const int passes = [] { const char *e = getenv("LEANN_VAMANA_PASSES"); int v = e ? atoi(e) : 1; return v >= 1 && v <= 3 ? v : 1; }();
+    for (int p = 1; rc == LEANN_OK && p < passes && h->kind == LEANN_BACKEND_DISKANN && n_existing == 0 && n > 1; p++)
+        rc = builder_insert_range(b, {}, 0, n, true);
     if (rc == LEANN_OK && b.lv.P && n) { // fold what is still pending into the lists (DiskANN's final trim)
         const float alpha = h->alpha;
         hipLaunchKernelGGL(reverse_merge_kernel, dim3(256 * 16), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, 0u, (const uint64_t *)nullptr,
