@@ -569,6 +569,7 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
         if (need <= cap) return 0;
         (void)hipFree(*p);
         *p = nullptr;
+        cap = 0;
         if (hipMalloc(p, need * elt) != hipSuccess) { leann_set_error("hipMalloc(%zu) failed", need * elt); return 1; }
         cap = need;
         return 0;
