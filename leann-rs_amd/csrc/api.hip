@@ -706,7 +706,7 @@ struct PendingQuery {
     float *dists;
     size_t *n_out;
     int rc = 0;
-    bool done = false;
+    bool done = false, answered = false;
     std::string err;
 };
 struct Coalescer {
@@ -739,6 +739,7 @@ struct Coalescer {
             std::map<std::pair<size_t, size_t>, std::vector<PendingQuery *>> groups;
             for (auto *p : batch) groups[{p->k, p->ef}].push_back(p);
             const size_t d = h->g.d;
+            try { // (an allocation failure in here must reach the callers as an error, not end the process from a library thread)
             for (auto &kv : groups) {
                 auto &g = kv.second;
                 const size_t nq = g.size(), k = kv.first.first;
@@ -757,9 +758,14 @@ struct Coalescer {
                     }
                     g[i]->rc = rc;
                     g[i]->err = err;
+                    g[i]->answered = true;
                 }
                 n_launches++;
                 n_queries += nq;
+            }
+            } catch (const std::exception &e) {
+                for (auto *p : batch)
+                    if (!p->answered) { p->rc = LEANN_ERR_DEVICE; p->err = std::string("request coalescing: ") + e.what(); *p->n_out = 0; }
             }
             lk.lock();
             recent_callers = batch.size() + queue.size();
