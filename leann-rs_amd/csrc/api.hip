@@ -521,7 +521,7 @@ extern "C" int leann_backend_search_filtered_exact_batch_device(const leann_back
     return leann_internal_filtered_exact(h->g.X, h->g.n, h->g.d, h->g.ld, d_queries, nq, top_k, d_allow, allow_stride, h->key_offset, d_keys,
                                          d_dists, d_counts, st);
 }
-static int search_filtered_batch_host(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
+static int search_filtered_batch_host_impl(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
                                       const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, int mode,
                                       const leann_filter *flt) {
     leann_backend *h = const_cast<leann_backend *>(hc);
@@ -692,6 +692,17 @@ static int search_filtered_batch_host(const leann_backend *hc, const float *quer
         return LEANN_ERR_OVERFLOW;
     }
     return LEANN_OK;
+}
+
+static int search_filtered_batch_host(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
+                                      const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, int mode,
+                                      const leann_filter *flt) {
+    try { // std::bad_alloc and friends must not cross the C ABI (every host-pointer search entry point funnels through here)
+        return search_filtered_batch_host_impl(hc, queries, nq, top_k, complexity, allow, allow_stride, keys, dists, counts, mode, flt);
+    } catch (const std::exception &e) {
+        leann_set_error("search: %s", e.what());
+        return LEANN_ERR_DEVICE;
+    }
 }
 
 // ---- request coalescing --------------------------------------------------------------
