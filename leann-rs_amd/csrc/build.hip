@@ -738,9 +738,20 @@ static int alloc_graph_arrays(leann_backend *h, uint64_t level_seed) {
 
 static constexpr uint64_t LEVEL_SEED = 0x5EED0003ull;
 
+static int build_device_impl(int backend, const float *d_vectors, size_t n, size_t dims, size_t ld, size_t graph_degree, size_t complexity,
+                             int device, uint64_t key_offset, int take_copy, leann_backend **out);
 extern "C" int leann_backend_build_device(int backend, const float *d_vectors, size_t n, size_t dims, size_t ld,
                                           size_t graph_degree, size_t complexity, int device, uint64_t key_offset,
                                           int take_copy, leann_backend **out) {
+    try { // host-side bookkeeping of the builder allocates (insertion order, level tables): nothing may be thrown across the C ABI
+        return build_device_impl(backend, d_vectors, n, dims, ld, graph_degree, complexity, device, key_offset, take_copy, out);
+    } catch (const std::exception &e) {
+        leann_set_error("build: %s", e.what());
+        return LEANN_ERR_DEVICE;
+    }
+}
+static int build_device_impl(int backend, const float *d_vectors, size_t n, size_t dims, size_t ld, size_t graph_degree, size_t complexity,
+                             int device, uint64_t key_offset, int take_copy, leann_backend **out) {
     if (!out || (n && !d_vectors) || dims == 0 || dims > 4096 || ld < dims || (ld & 3) || n >= (1ull << 31)) {
         leann_set_error("leann_backend_build_device: invalid arguments (n=%zu dims=%zu ld=%zu)", n, dims, ld);
         return LEANN_ERR_INVALID;
