@@ -60,7 +60,9 @@ int leann_backend_open(const char *index_path_stem, int backend, size_t dims,
 /* ---- BackendSearcher::search(&self, query, top_k, complexity)  src/backend/traits.rs:16-21 ----
  * Caller allocates keys/dists[top_k]; the first *n_out are filled, best first; *n_out <= top_k
  * (short results allowed, src/index/searcher.rs:139-143).  ef = max(complexity, top_k)
- * (diskann.rs:54).  Unlike hnsw.rs:83 `complexity` is honoured for HNSW too. */
+ * (diskann.rs:54).  Unlike hnsw.rs:83 `complexity` is honoured for HNSW too; with LEANN_HNSW_REFERENCE_EF=1 in the environment
+ * when the handle is made, an HNSW handle behaves like the reference instead: ef = max(64, top_k) whatever `complexity` says
+ * (expansion_search: 64, hnsw.rs:49; `_complexity` unused, :83). */
 int leann_backend_search(const leann_backend *h, const float *query, size_t top_k,
                          size_t complexity, uint64_t *keys, float *dists, size_t *n_out);
 
@@ -263,6 +265,21 @@ int leann_merge_topk_device(const uint64_t *d_keys, const float *d_dists, const 
                             uint64_t *d_out_keys, float *d_out_dists, uint32_t *d_out_counts,
                             void *stream);
 
+/* ---- hybrid rerank for batches (BASELINE configs[4]: DiskANN + hybrid BM25 rerank) ------------------------------------------------
+ * The hybrid branch of IndexSearcher::search_with_options (src/index/searcher.rs:146-169) + hybrid_rerank (src/index/bm25.rs:135-170)
+ * for nq queries at once, on the lists a leann_backend_search_batch_device call with top_k = fetch_k = 5 * top_k left in HBM:
+ * BM25-only hits of bm25_top (the first min(fetch_k, count) positives) are appended with vector score 0.0, both score lists are
+ * min-max normalised (the BM25 side over ALL n_docs scores), blended alpha * v + (1 - alpha) * b and stable-sorted descending;
+ * the first top_k entries are returned (unused tail: UINT64_MAX / -inf).  Every f32 operation in the reference's order.
+ * BM25 scores arrive SPARSE, as the host's Bm25Scorer::search produces them: per query `d_bm25_count[q]` positives (position, score),
+ * sorted by score descending, ties by position ascending (Rust's stable sort, bm25.rs:118), rows `bm25_stride` entries apart; every
+ * other passage scores 0.0.  compat_polarity != 0: the backend's DISTANCES enter the blend as the reference has it (the
+ * worst ANN hit gets the largest vector term); 0: corrected, 1 - dist.  fetch_k <= 256. */
+int leann_hybrid_rerank_device(const uint64_t *d_keys, const float *d_dists, const uint32_t *d_counts, size_t nq, size_t fetch_k,
+                               const uint32_t *d_bm25_pos, const float *d_bm25_score, const uint32_t *d_bm25_count,
+                               size_t bm25_stride, size_t n_docs, float alpha, int compat_polarity, size_t top_k,
+                               uint64_t *d_out_keys, float *d_out_scores, uint32_t *d_out_counts, void *stream);
+
 /* ---- sharded indexes (the reference has no counterpart: IndexSearcher owns one Box<dyn BackendSearcher>,
  * src/index/searcher.rs:68) --------------------------------------------------------------------------------------------------
  * One process, G devices: the composite handle leann_backend_open returns for a device list, or built here from rows / handles.
@@ -286,7 +303,8 @@ int leann_sharded_as_backend(leann_sharded *s, leann_backend **out);
 int leann_rccl_get_unique_id(void *id128);
 int leann_sharded_attach(leann_backend *local_shard, const void *unique_id128, int world, int rank, size_t total_rows,
                          leann_sharded **out);
-/* d_stats: optional per-query counters, [n_shards x nq x 4] (one process) / [nq x 4] (RCCL: the local shard's) */
+/* d_stats: optional per-query counters [nq x 4], the layout of leann_backend_search_batch_device: one process — evaluations and
+ * hops summed over the shards, visited-set level = the highest any shard needed; RCCL — the local shard's */
 int leann_sharded_search_batch_device(const leann_sharded *s, const float *d_queries, size_t nq, size_t top_k, size_t complexity,
                                       uint64_t *d_keys, float *d_dists, uint32_t *d_counts, uint32_t *d_stats, void *stream);
 int leann_sharded_search_batch_device_async(const leann_sharded *s, const float *d_queries, size_t nq, size_t top_k,
@@ -296,6 +314,10 @@ int leann_sharded_wait(const leann_sharded *s, uint64_t ticket, void *stream); /
 size_t leann_sharded_len(const leann_sharded *s);    /* rows over all shards */
 size_t leann_sharded_shards(const leann_sharded *s);
 void leann_sharded_close(leann_sharded *s);
+
+/* Environment knobs (LEANN_COALESCE, LEANN_HNSW_REFERENCE_EF, the LEANN_DEBUG_* test hooks) are read ONCE, when the library is first
+ * used — no search call touches the environment.  A test that changes one of them afterwards calls this to have it read again. */
+void leann_debug_reload_env(void);
 
 /* raw device memory helpers so that non-torch hosts (the C++ CLI, ctypes tests) need no HIP binding */
 int leann_device_count(int *n);

@@ -32,6 +32,9 @@ class SearchStats(C.Structure):
 SIGNATURES = {
     "leann_last_error": (C.c_char_p, []),
     "leann_version": (C.c_char_p, []),
+    "leann_debug_reload_env": (None, []),
+    "leann_hybrid_rerank_device": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int,
+                                            C.c_size_t, vp, vp, vp, vp]),
     "leann_backend_open": (C.c_int, [C.c_char_p, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(vp)]),
     "leann_backend_search": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, u64p, f32p, C.POINTER(C.c_size_t)]),
     "leann_backend_search_batch": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p, u32p]),

@@ -48,6 +48,40 @@ void leann_log(int level, const char *fmt, ...) {
 }
 extern "C" const char *leann_version(void) { return "leann-rs_amd 0.1 (gfx950)"; }
 
+// ---- environment knobs: read once (internal.h) -----------------------------------------------------
+static LeannKnobs *read_knobs_from_env() {
+    LeannKnobs *k = new LeannKnobs();
+    auto num = [](const char *name, int lo, int hi) { const char *e = getenv(name); if (!e || !*e) return 0; int v = atoi(e); return v >= lo && v <= hi ? v : 0; };
+    auto flag = [](const char *name) { const char *e = getenv(name); return e && *e && strcmp(e, "0") != 0; };
+    k->hash_bits = num("LEANN_DEBUG_HASH_BITS", 6, 15);
+    k->nw = num("LEANN_DEBUG_NW", 1, 64);
+    k->gpool_bits = num("LEANN_DEBUG_GPOOL_BITS", 6, 31);
+    k->gpool2_bits = num("LEANN_DEBUG_GPOOL2_BITS", 6, 31);
+    k->no_feat256 = flag("LEANN_DEBUG_NO_FEAT256");
+    k->no_zero_copy = flag("LEANN_DEBUG_NO_ZERO_COPY");
+    k->no_emit = flag("LEANN_DEBUG_NO_EMIT");
+    k->fused_v1 = flag("LEANN_DEBUG_FUSED_V1");
+    k->no_list = flag("LEANN_RECOMPUTE_NO_LIST");
+    k->no_tiled = flag("LEANN_RECOMPUTE_NO_TILED");
+    k->hnsw_reference_ef = flag("LEANN_HNSW_REFERENCE_EF");
+    if (const char *e = getenv("LEANN_COALESCE")) k->coalesce_off = !strcmp(e, "off") || !strcmp(e, "0");
+    if (const char *e = getenv("LEANN_STAMP_BUF")) k->stamp_buf = strtoull(e, nullptr, 0);
+    return k;
+}
+static std::atomic<const LeannKnobs *> g_knobs{nullptr};
+const LeannKnobs &leann_knobs() {
+    const LeannKnobs *k = g_knobs.load(std::memory_order_acquire);
+    if (!k) {
+        LeannKnobs *fresh = read_knobs_from_env();
+        const LeannKnobs *expected = nullptr;
+        if (g_knobs.compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) k = fresh;
+        else { delete fresh; k = expected; }
+    }
+    return *k;
+}
+// test hook: re-read the environment (the previous struct is left alive on purpose: a search in flight may still be reading it)
+extern "C" void leann_debug_reload_env(void) { g_knobs.store(read_knobs_from_env(), std::memory_order_release); }
+
 // ---- raw device helpers ---------------------------------------------------------------------------
 extern "C" int leann_device_count(int *n) {
     int c = 0;
@@ -93,12 +127,8 @@ static void ws_free(Workspace *w) {
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }
-static uint32_t debug_bits(const char *name, uint32_t lo, uint32_t hi, uint32_t dflt) { // test hooks: force tiny visited tables
-    if (const char *e = getenv(name)) {
-        int v = atoi(e);
-        if (v >= (int)lo && v <= (int)hi) return (uint32_t)v;
-    }
-    return dflt;
+static uint32_t debug_bits(int knob, uint32_t lo, uint32_t hi, uint32_t dflt) { // test hooks: force tiny visited tables
+    return knob >= (int)lo && knob <= (int)hi ? (uint32_t)knob : dflt;
 }
 // Pool 1: GPOOL_TABLES tables of 2^GPOOL_BITS slots (512 MB) for queries that outgrow their LDS table.  Pool 2, only when the
 // index has more rows than a pool-1 table holds at 75 % load: a few tables of >= (n + 128) / 0.75 slots each (<= 1 GiB in all), so
@@ -108,14 +138,14 @@ static int ensure_gpool(leann_backend *h) {
     if (h->gpool) return LEANN_OK;
     unsigned long long *p = nullptr, *p2 = nullptr;
     uint32_t *lock = nullptr, *lock2 = nullptr;
-    const uint32_t bits = debug_bits("LEANN_DEBUG_GPOOL_BITS", 6, GPOOL_BITS, GPOOL_BITS), tables = GPOOL_TABLES;
+    const uint32_t bits = debug_bits(leann_knobs().gpool_bits, 6, GPOOL_BITS, GPOOL_BITS), tables = GPOOL_TABLES;
     const size_t slots = (size_t)tables << bits;
     uint32_t bits2 = 0, tables2 = 0;
     const uint64_t need = h->g.n + 128;
     if (need > (1ull << bits) - (1ull << (bits - 2))) {
         bits2 = bits + 1;
         while (bits2 < 31 && (1ull << bits2) - (1ull << (bits2 - 2)) < need) bits2++;
-        bits2 = debug_bits("LEANN_DEBUG_GPOOL2_BITS", 6, 31, bits2);
+        bits2 = debug_bits(leann_knobs().gpool2_bits, 6, 31, bits2);
         const uint64_t per = 8ull << bits2;
         tables2 = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(2, (1ull << 30) / per));
     }
@@ -200,14 +230,19 @@ extern "C" int leann_backend_stats(const leann_backend *hc, leann_search_stats *
     return LEANN_OK;
 }
 
+// Reference-exact mode: the reference's HNSW searcher is opened with expansion_search = 64
+// (src/backend/hnsw.rs:49) and drops the caller's `complexity` (`_complexity`, :83), so every `leann search --complexity N` runs at
+// ef = max(64, top_k).  LEANN_HNSW_REFERENCE_EF=1 in the environment when the handle is made latches that behaviour into it (HNSW
+// handles only; DiskANN honours complexity in the reference too, diskann.rs:54).  Default: complexity is honoured.
+size_t leann_internal_effective_complexity(const leann_backend *h, size_t complexity) {
+    return (h->fixed_ef && h->kind == LEANN_BACKEND_HNSW) ? (size_t)h->fixed_ef : complexity;
+}
+
 // ---- kernel dispatch --------------------------------------------------------------------------------
 // LDS visited table: 4 workgroups per CU are register-limited anyway, so 32 KiB (8192 slots) per
 // query is free; larger beams take 64 / 128 KiB.  A query that outgrows it moves to the HBM pool.
 static uint32_t pick_hash_bits(uint32_t ef) {
-    if (const char *e = getenv("LEANN_DEBUG_HASH_BITS")) { // test hook: force tiny tables to exercise the HBM pool
-        int v = atoi(e);
-        if (v >= 6 && v <= 15) return (uint32_t)v;
-    }
+    if (const int v = leann_knobs().hash_bits) return (uint32_t)v; // test hook: force tiny tables to exercise the HBM pool
     // measured on 10M x 768: ~20-25 distance evaluations per unit of ef on average, p99.9 ~ 50 x ef.
     // 4 workgroups per CU need <= 32 KiB tables; a 64 KiB table halves occupancy and throughput, so
     // beams up to 256 keep the 8 192-slot table and let the ~1 % heaviest queries migrate to HBM.
@@ -248,7 +283,7 @@ static int launch_search_NW(const GraphView &g, const SearchArgs &a, hipStream_t
 template <int T, int R>
 static int launch_search_T(const GraphView &g, const SearchArgs &a, hipStream_t st) {
     int nw = a.nq <= 384 ? 16 : a.nq <= 640 ? 8 : 4; // 10M x 768, ef = 56: 16 waves win up to 256 queries, 8 at 512, 4 from 768 on (scripts/exp/batch_sweep.py)
-    if (const char *e = getenv("LEANN_DEBUG_NW")) nw = atoi(e);
+    if (const int v = leann_knobs().nw) nw = v;
     if (nw >= 16) return launch_search_NW<T, R, 16>(g, a, st);
     if (nw >= 8) return launch_search_NW<T, R, 8>(g, a, st);
     return launch_search_NW<T, R, 4>(g, a, st);
@@ -258,7 +293,7 @@ template <int T, int R>
 static int launch_search_feat(const GraphView &g, const SearchArgs &a, hipStream_t st) {
     size_t lds;
     if (int rc = search_lds_checked(g, a, &lds, a.nq <= 512 ? 16 : 4)) return rc;
-    if (T == 1 && g.feat_h == 256 && !getenv("LEANN_DEBUG_NO_FEAT256")) { // four rows per wave instruction
+    if (T == 1 && g.feat_h == 256 && !leann_knobs().no_feat256) { // four rows per wave instruction
         if (a.nq <= 512) {
             if (a.allow) return launch_one(beam_search_feat256_filtered_kernel<1, 16>, 16 * 64, lds, g, a, st);
             return launch_one(beam_search_feat256_kernel<1, 16>, 16 * 64, lds, g, a, st);
@@ -302,7 +337,7 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
         if (a.ef < a.k) a.ef = a.k;
         // 520-B rows make this mode latency- rather than bandwidth-bound: favour occupancy (16 KiB visited table ->
         // 6-8 workgroups per CU) for narrow beams; heavier queries migrate to the HBM pool
-        a.hash_bits = getenv("LEANN_DEBUG_HASH_BITS") ? pick_hash_bits(a.ef) : (a.ef <= 64 ? 12u : pick_hash_bits(a.ef));
+        a.hash_bits = leann_knobs().hash_bits ? pick_hash_bits(a.ef) : (a.ef <= 64 ? 12u : pick_hash_bits(a.ef));
         int rc = ensure_gpool(h);
         if (rc) return rc;
         set_pool_args(h, a);
@@ -324,7 +359,7 @@ int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st)
     // do not hide a hop's dependent phases behind their own transfer: narrow beams take the 16 KiB table (the heaviest queries
     // move to the HBM pool).  10M rows, ef = 64: 128-d 2.41 -> 3.10 M queries/s, 256-d 2.16 -> 2.72 M, 384-d 1.66 -> 1.85 M, 512-d
     // unchanged; 768-d and wider are bound by HBM either way and keep the larger table (scripts/exp/dims_sweep.py).
-    a.hash_bits = (h->g.ld <= 512 && a.ef <= 64 && !a.q_rows && !getenv("LEANN_DEBUG_HASH_BITS")) ? 12u : pick_hash_bits(a.ef);
+    a.hash_bits = (h->g.ld <= 512 && a.ef <= 64 && !a.q_rows && !leann_knobs().hash_bits) ? 12u : pick_hash_bits(a.ef);
     int rc = ensure_gpool(h);
     if (rc) return rc;
     set_pool_args(h, a);
@@ -374,7 +409,7 @@ extern "C" int leann_backend_search_filtered_batch_device(const leann_backend *h
         HIP_CHECK_RET(hipMemsetAsync(d_counts, 0, nq * 4, st));
         return LEANN_OK;
     }
-    if (h->sharded) // composite handle: fan out, gather, merge (shard.hip); d_stats is [shards x nq x 4] there
+    if (h->sharded) // composite handle: fan out, gather, merge (shard.hip); d_stats stays [nq x 4]: summed over the shards
         return leann_internal_sharded_search(h->sharded, d_queries, nq, top_k, complexity, d_allow, allow_stride, d_keys, d_dists, d_counts,
                                              d_stats, st, nullptr);
     SearchArgs a{};
@@ -382,7 +417,7 @@ extern "C" int leann_backend_search_filtered_batch_device(const leann_backend *h
     a.ldq = h->g.d;
     a.nq = (uint32_t)nq;
     a.k = (uint32_t)top_k;
-    a.ef = (uint32_t)std::max(complexity, top_k);
+    a.ef = (uint32_t)std::max(leann_internal_effective_complexity(h, complexity), top_k);
     a.target_level = 0;
     a.key_offset = h->key_offset;
     a.out_keys = d_keys;
@@ -392,8 +427,8 @@ extern "C" int leann_backend_search_filtered_batch_device(const leann_backend *h
     a.allow = d_allow;
     a.allow_stride = allow_stride;
 #ifdef LEANN_STAMPS
-    if (const char *e = getenv("LEANN_STAMP_BUF")) { // diagnostic build: [nq x 8] u64 device buffer address in the environment
-        a.out_nexp = reinterpret_cast<uint32_t *>(strtoull(e, nullptr, 0));
+    if (const unsigned long long e = leann_knobs().stamp_buf) { // diagnostic build: [nq x 8] u64 device buffer address in the environment
+        a.out_nexp = reinterpret_cast<uint32_t *>(e);
         a.exp_cap = 0xFEED;
     }
 #endif
@@ -560,7 +595,7 @@ static int search_filtered_batch_host_impl(const leann_backend *hc, const float 
         }
     }
     const size_t d = h->g.d, qf = nq * d, no = nq * top_k;
-    const size_t ns = h->sharded ? leann_internal_sharded_count(h->sharded) : 1; // composite handle: per-shard counters
+    const size_t ns = 1; // (a composite handle reduces its per-shard counters to [nq x 4] itself, shard.hip)
     if (h->sharded && (exact || flt)) {
         leann_set_error("exact / registered-filter search is not available on a sharded handle (the in-traversal filter is)");
         return fail(LEANN_ERR_UNSUPPORTED);
@@ -577,7 +612,7 @@ static int search_filtered_batch_host_impl(const leann_backend *hc, const float 
     // Small call on a plain handle: zero-copy through the workspace's pinned block (internal.h).  Layout, 16-byte aligned pieces:
     const size_t o_keys = (qf * 4 + 15) & ~(size_t)15, o_dists = o_keys + no * 8, o_counts = (o_dists + no * 4 + 15) & ~(size_t)15,
                  o_stats = o_counts + ((nq * 4 + 15) & ~(size_t)15), pin_bytes = o_stats + nq * 16;
-    bool zero_copy = !h->sharded && !exact && pin_bytes <= ((size_t)256 << 10) && !getenv("LEANN_DEBUG_NO_ZERO_COPY");
+    bool zero_copy = !h->sharded && !exact && pin_bytes <= ((size_t)256 << 10) && !leann_knobs().no_zero_copy;
     if (zero_copy && w->cap_pin < pin_bytes) {
         if (w->pin) (void)hipHostFree(w->pin);
         w->pin = nullptr;
@@ -620,7 +655,7 @@ static int search_filtered_batch_host_impl(const leann_backend *hc, const float 
     a.ldq = (uint32_t)d;
     a.nq = (uint32_t)nq;
     a.k = (uint32_t)top_k;
-    a.ef = (uint32_t)std::max(complexity, top_k);
+    a.ef = (uint32_t)std::max(leann_internal_effective_complexity(h, complexity), top_k);
     a.key_offset = h->key_offset;
     a.out_keys = zero_copy ? reinterpret_cast<uint64_t *>(w->pin + o_keys) : w->d_keys;
     a.out_dists = zero_copy ? reinterpret_cast<float *>(w->pin + o_dists) : w->d_dists;
@@ -824,8 +859,7 @@ extern "C" int leann_backend_set_coalescing(leann_backend *h, uint32_t wait_us, 
 // queued up while a batch ran leaves at once) and queues behind it; a
 // caller that is alone is answered directly, at the latency of one launch.
 static std::shared_ptr<Coalescer> auto_coalescer(leann_backend *h) {
-    static const bool enabled = [] { const char *e = getenv("LEANN_COALESCE"); return !(e && (!strcmp(e, "off") || !strcmp(e, "0"))); }();
-    if (!enabled) return nullptr;
+    if (leann_knobs().coalesce_off) return nullptr;
     {
         std::lock_guard<std::mutex> lk(h->mu);
         if (h->coalesce_mode != 0) return h->coalescer;

@@ -42,6 +42,7 @@ struct ListView {
     // ~600k prunes per 16k-point batch, each gathering 64+ rows (0.4 MB at 1536-d) — 67 % of a 10M x 1536 build.
     uint32_t *pend; float *pendd;
     uint32_t P;
+    uint32_t two_stage; // Vamana: occlude_list's two-stage RobustPrune (prune_core)
 };
 __device__ __forceinline__ void list_ptr(const ListView &lv, uint32_t node, uint32_t level, uint32_t **ids, float **ds,
                                          uint32_t *cap) {
@@ -137,26 +138,53 @@ __device__ __forceinline__ void gram_lower(const float *__restrict__ X, uint32_t
 
 __device__ uint32_t prune_core(const float *__restrict__ X, uint32_t ld, const uint32_t *c_id, const float *c_d,
                                uint32_t nc, uint32_t limit, float alpha, float *tri /* TRI_ELEMS floats, LDS */,
-                               uint32_t *s_sel /* [64] LDS */, uint32_t *s_cnt /* LDS */) {
+                               uint32_t *s_sel /* [64] LDS */, uint32_t *s_cnt /* LDS */, bool stage1) {
     float *stage = static_cast<float *>(__builtin_assume_aligned(tri, 16)); // [KC][LDW] aliased: dead before tri is written
     const int tid = threadIdx.x;
     if (nc <= 32) gram_lower<2>(X, ld, c_id, nc, tri, stage);       // work ~ nc^2: small lists use small tiles
     else if (nc <= 64) gram_lower<4>(X, ld, c_id, nc, tri, stage);
     else gram_lower<8>(X, ld, c_id, nc, tri, stage);
+    __shared__ uint8_t s_taken[NCMAX];
     if (tid < 64) { // wave 0: sequential walk over candidates, lanes = kept slots
         uint32_t ns = 0;
         int my = -1;
+        // Vamana, two-stage form (DiskANN's occlude_list): the FIRST walk over the whole pool keeps a candidate only if no kept
+        // one is at least as close to it as the point itself (alpha = 1: the diverse core, which reaches the far end of the pool before
+        // the list is full); only the slots still free after it are filled by the relaxed rule alpha * d(c, kept) <= d(c, p) -> drop.
+        // With the one-stage rule of the paper (Alg. 2) at alpha = 1.2 almost nothing is occluded on data of high intrinsic dimension, a
+        // list is simply the R nearest of the pool, and at R = 32 the graph stops being navigable as the corpus grows (recall@10 at
+        // L = 128, 256-d: 0.976 at 1M, 0.905 at 5M, 0.78 at 10M; scripts/exp/vamana_scale.py, profiles/r03_vamana_scale.md).
+        const bool two_stage = alpha > 1.0f && stage1;
+        if (two_stage)
+            for (uint32_t i = tid; i < nc; i += 64) s_taken[i] = 0;
         for (uint32_t i = 0; i < nc; i++) {
             const float di = c_d[i];
             bool bad = false;
             if (tid < (int)ns) {
                 float gdist = tri[i * (i - 1) / 2 + my];
-                bad = (alpha == 0.f) ? (gdist < di) : (alpha * gdist <= di);
+                bad = (alpha == 0.f) ? (gdist < di) : ((two_stage ? 1.0f : alpha) * gdist <= di);
             }
             if (!__any(bad)) {
                 if (tid == (int)ns) my = (int)i;
+                if (two_stage && tid == 0) s_taken[i] = 1;
                 ns++;
                 if (ns == limit) break;
+            }
+        }
+        if (two_stage && ns < limit) {
+            for (uint32_t i = 0; i < nc; i++) {
+                if (s_taken[i]) continue; // (uniform: every lane reads the same byte)
+                const float di = c_d[i];
+                bool bad = false;
+                if (tid < (int)ns) {
+                    const uint32_t hi = max(i, (uint32_t)my), lo = min(i, (uint32_t)my);
+                    bad = alpha * tri[hi * (hi - 1) / 2 + lo] <= di;
+                }
+                if (!__any(bad)) {
+                    if (tid == (int)ns) my = (int)i;
+                    ns++;
+                    if (ns == limit) break;
+                }
             }
         }
         if (tid < (int)ns) s_sel[tid] = (uint32_t)my;
@@ -248,7 +276,7 @@ __global__ void __launch_bounds__(256) select_kernel(const float *__restrict__ X
         nc = keep + take;
         __syncthreads();
     }
-    uint32_t ns = prune_core(X, ld, c_id, c_d, nc, msel, alpha, tri, s_sel, &s_cnt);
+    uint32_t ns = prune_core(X, ld, c_id, c_d, nc, msel, alpha, tri, s_sel, &s_cnt, lv.two_stage != 0);
     uint32_t *ids; float *ds; uint32_t cap;
     list_ptr(lv, q, level, &ids, &ds, &cap);
     for (uint32_t j = threadIdx.x; j < msel; j += 256) {
@@ -351,7 +379,7 @@ __global__ void __launch_bounds__(256) reverse_merge_kernel(const float *__restr
             c_d[i] = i < nc ? orderable_f32((uint32_t)(skey[i] >> 32)) : 0.f;
         }
         __syncthreads();
-        uint32_t ns = prune_core(X, ld, c_id, c_d, nc, cap, alpha, tri, s_sel, &s_cnt);
+        uint32_t ns = prune_core(X, ld, c_id, c_d, nc, cap, alpha, tri, s_sel, &s_cnt, lv.two_stage != 0);
         for (uint32_t j = threadIdx.x; j < cap; j += 256) {
             if (j < ns) {
                 uint32_t c = s_sel[j];
@@ -435,6 +463,8 @@ struct Builder {
     uint64_t *exp_keys = nullptr; uint32_t *exp_cnt = nullptr; // Vamana only
     void *cub_tmp = nullptr; size_t cub_bytes = 0;
     hipStream_t st = nullptr;
+    size_t batch_fraction = 8; // LEANN_BUILD_BATCH_FRACTION, read once per build
+    float alpha_now = 1.2f;    // Vamana: RobustPrune's alpha of the pass under way
     Builder() = default;
     Builder(const Builder &) = delete;
     ~Builder() { // every exit of build_on_device, including the error returns, releases the scratch and the stream
@@ -445,6 +475,13 @@ struct Builder {
         if (st) (void)hipStreamDestroy(st);
     }
 };
+// construction knobs are read once per build (a build takes seconds to minutes; the search path reads no environment at all)
+static int env_int(const char *name, int dflt, int lo, int hi) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return v >= lo && v <= hi ? v : dflt;
+}
 struct DevTmp { // small scoped device allocation
     void *p = nullptr;
     ~DevTmp() { (void)hipFree(p); }
@@ -463,7 +500,7 @@ static int link_level(Builder &b, const uint32_t *d_rows, uint32_t nq, uint32_t 
                       const uint32_t *cc, const uint64_t *ek = nullptr, const uint32_t *ec = nullptr) {
     leann_backend *h = b.h;
     const uint32_t efc = h->efc, msel = h->g.M; // M new links per point on every level (Malkov Alg. 1)
-    const float alpha = h->kind == LEANN_BACKEND_DISKANN ? h->alpha : 0.f;
+    const float alpha = h->kind == LEANN_BACKEND_DISKANN ? b.alpha_now : 0.f;
     hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, d_rows, nq, level, ck, cd, cc,
                        efc, msel, alpha, b.prop_key, b.prop_src, ek, ec, (uint32_t)EXPCAP);
     const uint32_t num = nq * msel;
@@ -514,7 +551,7 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
     (void)order_host_upper;
     leann_backend *h = b.h;
     const uint32_t efc = h->efc;
-    const bool hnsw = h->kind == LEANN_BACKEND_HNSW;
+    const bool hnsw = h->kind == LEANN_BACKEND_HNSW || h->nav_levels; // (leveled: entry layers above the base graph)
     size_t s = s0;
     const size_t bu_cap = (b.bmax / 16 + 64) * 16;
     while (s < n) {
@@ -522,7 +559,7 @@ static int builder_insert_range(Builder &b, const std::vector<uint32_t> &order_h
         // 1/8 (LEANN_BUILD_BATCH_FRACTION) of the points already linked.  With batches as large as the graph itself — the first
         // rule here — two thirds of a 50k-row index went in without seeing their batch mates and recall@10 at ef = 32 fell 1.6
         // points below the sequential builder's (tests/test_gpu_builder_quality.py); from ~130k rows on the cap is bmax anyway.
-        static const size_t frac = [] { const char *e = getenv("LEANN_BUILD_BATCH_FRACTION"); int v = e ? atoi(e) : 8; return (size_t)(v >= 1 ? v : 8); }();
+        const size_t frac = b.batch_fraction;
         size_t B = std::min<size_t>(std::min<size_t>(b.bmax, refine ? b.bmax : std::max<size_t>(1, s / frac)), n - s);
         const uint32_t Lmax = h->g.max_level;
         // ---- phase 1: searches (graph does not contain any point of the batch yet) ----------------
@@ -621,6 +658,7 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
     // for nodes < n_existing (append) or empty.
     Builder b;
     b.h = h;
+    b.batch_fraction = (size_t)env_int("LEANN_BUILD_BATCH_FRACTION", 8, 1, 1 << 20);
     const size_t n = h->g.n;
     BCHECK(hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking));
     b.lv.adj0 = const_cast<uint32_t *>(h->g.adj0);
@@ -639,7 +677,8 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
         // 10M x 1536, R = 64, recall@10 at L = 72 over 2 000 queries (scripts/exp/vamana_slack.sh): strict (0 pending) 185.8 s / 0.9600;
         // 4 pending 82.2 s / 0.9596; 8: 65.3 s / 0.9531; 16: 56.1 s / 0.9547.  Back-edges that wait are invisible to the construction
         // searches of later points, which costs about half a point of recall from 8 on; 4 keeps the strict rule's recall at 2.3x its speed.
-        static const uint32_t slack = [] { const char *e = getenv("LEANN_VAMANA_PENDING"); int v = e ? atoi(e) : 4; return (uint32_t)(v >= 0 && v <= 32 ? v : 4); }();
+        b.lv.two_stage = (uint32_t)env_int("LEANN_VAMANA_TWO_STAGE", 1, 0, 1);
+        const uint32_t slack = (uint32_t)env_int("LEANN_VAMANA_PENDING", 4, 0, 32);
         b.lv.P = slack;
         if (slack) {
             BCHECK(hipMalloc((void **)&b.pend, std::max<size_t>(n, 1) * slack * 4));
@@ -657,7 +696,7 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
     size_t s0 = n_existing;
     if (n_existing == 0 && n > 0) {
         uint32_t first = 0;
-        if (h->kind == LEANN_BACKEND_DISKANN) {
+        if (h->kind == LEANN_BACKEND_DISKANN && !h->nav_levels) {
             // medoid: closest row to the mean direction, by the index metric (ties -> lower id)
             DevTmp t_mean, t_mk, t_ms, t_mc, t_part;
             const uint32_t S = 1024;
@@ -676,10 +715,11 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
             BCHECK(hipStreamSynchronize(b.st));
             first = (uint32_t)key;
         }
-        if (h->kind == LEANN_BACKEND_HNSW) first = insertion_order(b.order, 0, n);
+        const bool leveled = h->kind == LEANN_BACKEND_HNSW || h->nav_levels;
+        if (leveled) first = insertion_order(b.order, 0, n);
         else insertion_order(b.order, 0, n, &first);
         h->g.entry = first;
-        h->g.max_level = h->kind == LEANN_BACKEND_HNSW ? b.levels[first] : 0;
+        h->g.max_level = leveled ? b.levels[first] : 0;
         s0 = 1;
     } else {
         insertion_order(b.order, n_existing, n);
@@ -691,14 +731,21 @@ static int build_on_device(leann_backend *h, size_t n_existing, size_t bmax_hint
     BCHECK(hipMemcpyAsync(b.d_order, b.order.data(), n * 4, hipMemcpyHostToDevice, b.st));
     size_t bmax = bmax_hint ? bmax_hint : 16384;
     rc = builder_alloc_scratch(b, bmax);
+    const int passes = env_int("LEANN_VAMANA_PASSES", 1, 1, 3);
+    b.alpha_now = h->alpha;
+    if (passes > 1 && h->kind == LEANN_BACKEND_DISKANN) { // experiment knob: alpha of every pass but the last (DiskANN: 1.0), in 1/100
+        b.alpha_now = (float)env_int("LEANN_VAMANA_ALPHA1_PCT", (int)(h->alpha * 100.f + 0.5f), 100, 400) / 100.f;
+    }
     if (rc == LEANN_OK) rc = builder_insert_range(b, {}, s0, n);
     // DiskANN builds in two passes over the points (the second one re-links every point against the finished graph).  Optional here
     // (LEANN_VAMANA_PASSES=2), off by default — 10M x 1536: at R = 64 it doubles the build (82 -> 173 s) and buys nothing (recall@10 0.95
     // needs L = 76 instead of 72); at R = 32, where one pass is not enough for 10M clustered rows (recall 0.60 at L = 128), it lifts the
     // recall to 0.81 — still not a usable index, which is why the 10M benchmarks use R = 64.
-    static const int passes = [] { const char *e = getenv("LEANN_VAMANA_PASSES"); int v = e ? atoi(e) : 1; return v >= 1 && v <= 3 ? v : 1; }();
-    for (int p = 1; rc == LEANN_OK && p < passes && h->kind == LEANN_BACKEND_DISKANN && n_existing == 0 && n > 1; p++)
+    for (int p = 1; rc == LEANN_OK && p < passes && h->kind == LEANN_BACKEND_DISKANN && n_existing == 0 && n > 1; p++) {
+        if (p == passes - 1) b.alpha_now = h->alpha;
         rc = builder_insert_range(b, {}, 0, n, true);
+    }
+    b.alpha_now = h->alpha;
     if (rc == LEANN_OK && b.lv.P && n) { // fold what is still pending into the lists (DiskANN's final trim)
         const float alpha = h->alpha;
         hipLaunchKernelGGL(reverse_merge_kernel, dim3(256 * 16), dim3(256), 0, b.st, h->g.X, h->g.ld, b.lv, 0u, (const uint64_t *)nullptr,
@@ -716,7 +763,7 @@ static int alloc_graph_arrays(leann_backend *h, uint64_t level_seed) {
     std::vector<uint32_t> uo(nn, 0);
     uint64_t nu = 0;
     for (size_t i = 0; i < n; i++) {
-        levels[i] = h->kind == LEANN_BACKEND_HNSW ? (uint8_t)node_level(level_seed, i, h->g.M) : 0;
+        levels[i] = (h->kind == LEANN_BACKEND_HNSW || h->nav_levels) ? (uint8_t)node_level(level_seed, i, h->g.M) : 0;
         uo[i] = (uint32_t)nu;
         nu += levels[i];
     }
@@ -783,6 +830,7 @@ static int build_device_impl(int backend, const float *d_vectors, size_t n, size
     h->g.ld = (uint32_t)ld;
     h->g.M = (uint32_t)graph_degree;
     h->g.M0 = backend == LEANN_BACKEND_HNSW ? (uint32_t)(2 * graph_degree) : (uint32_t)graph_degree;
+    h->nav_levels = backend == LEANN_BACKEND_DISKANN && env_int("LEANN_VAMANA_NAV", 0, 0, 1) != 0;
     if (take_copy) {
         float *cp = nullptr;
         if (hipMalloc((void **)&cp, std::max<size_t>(n * ld, 4) * 4) != hipSuccess ||

@@ -24,6 +24,22 @@ struct Workspace { // staging of the host-pointer API; one per concurrent caller
     hipStream_t stream = nullptr;
 };
 
+// Environment knobs of the SEARCH path.  The environment is read ONCE — when the library is first used — into this struct; a search
+// call never calls getenv (it used to, five times per call: a 50-us call paid five environment scans, and getenv racing a setenv in a
+// multi-threaded Rust host is undefined behaviour).  Tests that flip a diagnostic knob on a live handle call leann_debug_reload_env().
+struct LeannKnobs {
+    int hash_bits = 0;      // LEANN_DEBUG_HASH_BITS: force the LDS visited table to 2^bits slots (6..15; 0 = automatic)
+    int nw = 0;             // LEANN_DEBUG_NW: waves per query (0 = by batch size)
+    int gpool_bits = 0, gpool2_bits = 0; // LEANN_DEBUG_GPOOL_BITS / _GPOOL2_BITS (0 = default sizes)
+    bool no_feat256 = false, no_zero_copy = false, no_emit = false, fused_v1 = false, no_list = false, no_tiled = false;
+    bool coalesce_off = false;       // LEANN_COALESCE=off|0
+    bool hnsw_reference_ef = false;  // LEANN_HNSW_REFERENCE_EF=1: HNSW handles opened from now on search with ef = 64 whatever
+                                     // `complexity` says, as the reference does (hnsw.rs:49 expansion_search: 64, :83 _complexity unused)
+    unsigned long long stamp_buf = 0; // LEANN_STAMP_BUF (diagnostic builds only)
+};
+const LeannKnobs &leann_knobs();
+extern "C" void leann_debug_reload_env(void);
+
 struct Coalescer;
 struct leann_sharded;
 struct leann_backend {
@@ -35,6 +51,8 @@ struct leann_backend {
     uint8_t *d_levels = nullptr;
     uint32_t efc = 64;
     float alpha = 1.2f;
+    uint32_t fixed_ef = leann_knobs().hnsw_reference_ef ? 64u : 0u; // reference-exact mode, latched when the handle is made (HNSW only)
+    bool nav_levels = false; // Vamana built with entry layers (build.hip); searches need nothing but g.max_level / g.entry
     uint64_t n_upper_lists = 0;
     std::mutex mu;
     std::vector<Workspace *> free_ws; // host-pointer API: one per concurrent caller
@@ -76,6 +94,7 @@ int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size
 extern "C" void leann_sharded_close(leann_sharded *s);
 
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st);
+size_t leann_internal_effective_complexity(const leann_backend *h, size_t complexity);
 
 // Candidate emission of the exhaustive searches (recompute_fstat.cuh, scan.hip): instead of writing an nq x rows score slab for a
 // separate top-k pass, a scoring kernel compares each score with the query's running k-th best (fixed for the launch) and appends

@@ -445,7 +445,7 @@ static size_t encode_lds_bytes(size_t hp, size_t dp, bool fused = false) { retur
 // the feature-stationary fused kernel serves the common shape (one token row per passage, h = 256, dims a multiple of 128);
 // LEANN_DEBUG_FUSED_V1 forces the general kernel (tests compare the two)
 static bool use_fstat(const leann_recompute *r) {
-    return r->L == 1 && !r->mask && r->h == 256 && r->dp % 128 == 0 && !getenv("LEANN_DEBUG_FUSED_V1");
+    return r->L == 1 && !r->mask && r->h == 256 && r->dp % 128 == 0 && !leann_knobs().fused_v1;
 }
 
 static int launch_encode(const leann_recompute *r, uint64_t row0, uint64_t rows, float *E, hipStream_t st,
@@ -691,7 +691,7 @@ extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, con
     // per-passage arithmetic, so the same scores as the masked pass over everything); LEANN_RECOMPUTE_NO_LIST=1 keeps the masked pass.
     uint32_t *list = nullptr;
     size_t n_list = 0;
-    if (d_allow_mask && use_fstat(r) && r->n < (1ull << 32) && !getenv("LEANN_RECOMPUTE_NO_LIST")) {
+    if (d_allow_mask && use_fstat(r) && r->n < (1ull << 32) && !leann_knobs().no_list) {
         int rc = leann_internal_compact_allow(d_allow_mask, r->n, &list, &n_list, (hipStream_t)stream);
         if (rc != LEANN_OK) return rc;
         if (n_list > r->n / 2) { // barely selective: the masked pass reads the fragment-major feature copy and skips the gather
@@ -726,7 +726,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     {
         // with candidate emission only the first chunk needs a score slab: 16k rows fix a first k-th-best bound, the next 496k
         // tighten it (~k * 496k / 16k survivors per query), everything else goes through ONE persistent launch
-        const bool emit_schedule = emit_ok && use_fstat(r) && !getenv("LEANN_DEBUG_NO_EMIT");
+        const bool emit_schedule = emit_ok && use_fstat(r) && !leann_knobs().no_emit;
         size_t pos = 0, len = emit_schedule ? (size_t)16 << 10 : (size_t)128 << 10;
         while (pos < N) {
             size_t rows = std::min(len, N - pos);
@@ -744,7 +744,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     const size_t cand_len = std::max<size_t>(total_segs * k, k);
     leann_recompute *rw = const_cast<leann_recompute *>(r);
     std::lock_guard<std::mutex> scratch_lock(rw->mu);
-    if (use_fstat(r) && !idx && !rw->Ft && r->n >= 4096 && !getenv("LEANN_RECOMPUTE_NO_TILED")) {
+    if (use_fstat(r) && !idx && !rw->Ft && r->n >= 4096 && !leann_knobs().no_tiled) {
         // first exhaustive search on this handle: keep a fragment-major copy of the features (+ n * h * 2 bytes; if HBM is short
         // the kernel reads the caller's row-major array instead, ~10 % slower)
         const uint64_t n_pad = (r->n + 255) / 256 * 256 + 256;
@@ -772,7 +772,7 @@ static int recompute_search_impl(const leann_recompute *r, const float *d_querie
     uint64_t *candA = rw->sCandA, *candB = rw->sCandB, *best = rw->sBest;
     // chunks after the first emit their few survivors straight from the fused kernel (no score slab, no segment sort)
     const uint32_t EMIT_CAP = std::max<uint32_t>(8192, 32 * k); // expected survivors per query ~ k * rows / rows_seen (x19 after 512k of 10M rows)
-    const bool emit = emit_ok && use_fstat(r) && n_chunks > 1 && k <= 1024 && !getenv("LEANN_DEBUG_NO_EMIT");
+    const bool emit = emit_ok && use_fstat(r) && n_chunks > 1 && k <= 1024 && !leann_knobs().no_emit;
     CandEmit em{};
     uint32_t *d_overflow = nullptr;
     if (emit) {

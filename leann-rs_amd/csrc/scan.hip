@@ -505,7 +505,7 @@ static int scan_topk_impl(const float *d_rows, size_t n, size_t dims, size_t ld,
     // Pass 1 (emission): a 64k-row slab + segment top-k fixes a first k-th best per query; the following launches (448k rows, then
     // everything else) emit only the scores that reach it (CandEmit).  A candidate list that overflows (adversarial order) makes the
     // call repeat on pass 2, the slab path: geometric chunks 128k, 512k, 2M, ... (slab <= 2 GiB) with threshold-pruned segment sorts.
-    for (int pass = (n > ((size_t)64 << 10) && !getenv("LEANN_DEBUG_NO_EMIT")) ? 1 : 2; pass <= 2; pass++) {
+    for (int pass = (n > ((size_t)64 << 10) && !leann_knobs().no_emit) ? 1 : 2; pass <= 2; pass++) {
         const bool emit = pass == 1;
         std::vector<std::pair<size_t, size_t>> chunks;
         {

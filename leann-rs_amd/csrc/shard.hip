@@ -112,6 +112,19 @@ struct leann_sharded {
 };
 
 static size_t block_bytes(size_t nq, size_t k) { return (nq * k * 12 + nq * 4 + 15) & ~(size_t)15; }
+// per-query counters of a composite handle: the caller's d_stats is [nq x 4] like a plain handle's (include/leann_backend.h) —
+// evaluations and hops summed over the shards, the visited-set level the highest any shard needed
+__global__ void reduce_shard_stats_kernel(const uint32_t *__restrict__ per_shard /* [G x nq x 4] */, uint32_t G, uint32_t nq,
+                                          uint32_t *__restrict__ out /* [nq x 4] */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * 4) return;
+    uint32_t acc = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t v = per_shard[(size_t)g * nq * 4 + i];
+        acc = (i & 3) == 3 ? max(acc, v) : acc + v;
+    }
+    out[i] = acc;
+}
 static int grow_dev(void **p, size_t *cap, size_t bytes) {
     if (bytes <= *cap) return LEANN_OK;
     (void)hipFree(*p); // (synchronises the device: nothing still reads the old block)
@@ -454,8 +467,9 @@ extern "C" int leann_sharded_attach(leann_backend *local, const void *unique_id1
 
 // ---- search ---------------------------------------------------------------------------------------------------------------------
 // d_queries [nq x dims] and the outputs live on the handle's first device (RCCL mode: the rank's device).  d_stats: optional
-// [G x nq x 4] (one-process mode) / [nq x 4] (RCCL mode: the local shard's).  The traversal is queued behind `stream`; exchange and
-// merge run on the handle's own stream.  ticket == nullptr: `stream` also waits for the merge (results are ordered on `stream`).
+// [nq x 4] — one-process mode: summed over the shards (reduce_shard_stats_kernel, after the merge); RCCL mode: the local shard's.
+// The traversal is queued behind `stream`; exchange and merge run on the handle's own stream.  ticket == nullptr: `stream` also waits
+// for the merge (results are ordered on `stream`).
 int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size_t nq, size_t top_k, size_t complexity,
                                   const uint8_t *d_allow, size_t allow_stride, uint64_t *d_keys, float *d_dists, uint32_t *d_counts,
                                   uint32_t *d_stats, hipStream_t st, uint64_t *ticket) {
@@ -470,7 +484,8 @@ int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size
     ShardSlot &sl = s->slots[tk & 1];
     const size_t blk = block_bytes(nq, top_k), koff = 0, doff = nq * top_k * 8, coff = nq * top_k * 12;
     if (int rc = grow_dev((void **)&sl.gather, &sl.cap_gather, G * blk)) return rc;
-    const size_t allow_total = d_allow ? (allow_stride ? allow_stride * nq : (s->total_rows + 7) / 8) : 0;
+    if (d_stats && !s->rccl)
+        if (int rc = grow_dev((void **)&sl.stats, &sl.cap_stats, G * nq * 16)) return rc;
     HIP_CHECK_RET(hipEventRecord(sl.ev_q, st)); // the queries (and the allow-bitmaps) are ready
     if (s->rccl) {
         const RcclApi *api = rccl_api();
@@ -494,7 +509,7 @@ int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size
             if (sl.used) HIP_CHECK_RET(hipStreamWaitEvent(sd.st, sl.done, 0)); // the merge that last read this slot has finished
             const bool remote = sd.device != s->primary;
             const float *q = d_queries;
-            const uint8_t *allow = d_allow;
+            const uint8_t *allow_g = d_allow ? d_allow + sd.lo / 8 : nullptr; // the shard's slice of the bitmap(s): its first position is bit 0
             unsigned char *blkp = sl.gather + g * blk;
             if (remote) {
                 if (int rc = grow_dev((void **)&sd.d_q, &sd.cap_q, nq * s->dims * 4)) return rc;
@@ -502,24 +517,26 @@ int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size
                 HIP_CHECK_RET(hipMemcpyPeerAsync(sd.d_q, sd.device, d_queries, s->primary, nq * s->dims * 4, sd.st));
                 q = sd.d_q;
                 blkp = sd.d_out;
-                if (d_allow) {
-                    if (int rc = grow_dev((void **)&sd.d_allow, &sd.cap_allow, allow_total)) return rc;
-                    HIP_CHECK_RET(hipMemcpyPeerAsync(sd.d_allow, sd.device, d_allow, s->primary, allow_total, sd.st));
-                    allow = sd.d_allow;
+                if (d_allow) { // only the bytes this shard reads travel: [lo / 8, ceil(hi / 8)) of the shared bitmap, or of the strided block
+                    const size_t slice = (sd.h->g.n + 7) / 8;
+                    const size_t span = allow_stride ? allow_stride * (nq - 1) + slice : slice;
+                    if (int rc = grow_dev((void **)&sd.d_allow, &sd.cap_allow, span)) return rc;
+                    HIP_CHECK_RET(hipMemcpyPeerAsync(sd.d_allow, sd.device, d_allow + sd.lo / 8, s->primary, span, sd.st));
+                    allow_g = sd.d_allow;
                 }
             }
             uint32_t *stats_g = nullptr;
-            if (d_stats && !remote) stats_g = d_stats + g * nq * 4;
+            if (d_stats && !remote) stats_g = sl.stats + g * nq * 4;
             if (d_stats && remote) {
                 if (int rc = grow_dev((void **)&sd.d_stats, &sd.cap_stats, nq * 16)) return rc;
                 stats_g = sd.d_stats;
             }
-            int rc = leann_backend_search_filtered_batch_device(sd.h, q, nq, top_k, complexity, allow ? allow + sd.lo / 8 : nullptr, allow_stride,
+            int rc = leann_backend_search_filtered_batch_device(sd.h, q, nq, top_k, complexity, allow_g, allow_stride,
                                                                 (uint64_t *)(blkp + koff), (float *)(blkp + doff), (uint32_t *)(blkp + coff),
                                                                 stats_g, sd.st);
             if (rc) { (void)hipSetDevice(s->primary); return rc; }
             if (remote) HIP_CHECK_RET(hipMemcpyPeerAsync(sl.gather + g * blk, s->primary, sd.d_out, sd.device, blk, sd.st));
-            if (remote && d_stats) HIP_CHECK_RET(hipMemcpyPeerAsync(d_stats + g * nq * 4, s->primary, sd.d_stats, sd.device, nq * 16, sd.st));
+            if (remote && d_stats) HIP_CHECK_RET(hipMemcpyPeerAsync(sl.stats + g * nq * 4, s->primary, sd.d_stats, sd.device, nq * 16, sd.st));
             HIP_CHECK_RET(hipEventRecord(sd.ev[tk & 1], sd.st));
         }
         HIP_CHECK_RET(hipSetDevice(s->primary));
@@ -528,6 +545,11 @@ int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size
     int rc = leann_internal_merge_strided(sl.gather + koff, sl.gather + doff, sl.gather + coff, blk, blk, blk, G, nq, top_k, top_k, 0, d_keys,
                                           d_dists, d_counts, s->xstream);
     if (rc) return rc;
+    if (d_stats && !s->rccl) {
+        hipLaunchKernelGGL(reduce_shard_stats_kernel, dim3((unsigned)((nq * 4 + 255) / 256)), dim3(256), 0, s->xstream, sl.stats, (uint32_t)G,
+                           (uint32_t)nq, d_stats);
+        HIP_CHECK_RET(hipGetLastError());
+    }
     HIP_CHECK_RET(hipEventRecord(sl.done, s->xstream));
     sl.used = true;
     if (ticket) *ticket = tk;

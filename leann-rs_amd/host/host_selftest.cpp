@@ -73,6 +73,7 @@ int main(int argc, char **argv) {
             SearchOptions opts(top_k, 64);
             const bool hybrid = c.get("hybrid") && c.get("hybrid")->b;
             if (hybrid) opts.with_hybrid(c.get("query_text")->s, (float)c.get("alpha")->as_f64());
+            if (c.get("compat_polarity")) opts.with_compat_polarity(c.get("compat_polarity")->b);
             if (c.get("filter") && c.get("filter")->is_string()) {
                 auto f = MetadataFilter::parse(c.get("filter")->s);
                 if (f) opts.with_filter(*f);

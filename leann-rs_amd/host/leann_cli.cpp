@@ -21,6 +21,7 @@ struct SearchArgs {
     bool show_metadata = false, hybrid = false, auto_hybrid = true, expand = true;
     std::optional<std::string> filter;
     float hybrid_alpha = 0.7f;
+    bool compat_polarity = true; // additive: SURVEY.md N1 (see SearchOptions::compat_polarity)
     std::string format = "text";
     std::optional<std::string> query_prompt_template, embedding_mode, query_vector_file;
     std::string device = getenv("LEANN_DEVICES") ? getenv("LEANN_DEVICES") : "0"; // "0", or a list / range = sharded (leann_backend.h)
@@ -79,6 +80,7 @@ static int run_search(int argc, char **argv) {
         else if (name == "--auto-hybrid") a.auto_hybrid = parse_bool(val());
         else if (name == "--expand") a.expand = parse_bool(val());
         else if (name == "--hybrid-alpha") a.hybrid_alpha = std::stof(val());
+        else if (name == "--compat-polarity") a.compat_polarity = parse_bool(val());
         else if (name == "--format") { a.format = val(); if (a.format != "text" && a.format != "json") throw Error("invalid value '" + a.format + "' for '--format <FORMAT>' [possible values: text, json]"); }
         else if (name == "--embedding-api-key" || name == "--embedding-api-base" || name == "--embedding-host") (void)val();
         else if (name == "--query-prompt-template") a.query_prompt_template = val();
@@ -148,6 +150,7 @@ static int run_search(int argc, char **argv) {
         if (filter) opts.with_filter(*filter);
         if (filter && a.device_filter) opts.with_device_filter(*a.filter);
         if (use_hybrid) opts.with_hybrid(a.query, a.hybrid_alpha);
+        opts.with_compat_polarity(a.compat_polarity);
         results = searcher.search_with_options(q, opts);
     };
     // A pruned index (search.rs:151-167) recomputes embeddings at query time.  The reference scans every passage through the provider

@@ -446,10 +446,16 @@ struct SearchOptions {
     // :190-194).  `filter_key` names the filter for the bitmap cache (the CLI passes the filter text).
     bool device_filter = false;
     std::string filter_key;
+    // the reference hands the backend's DISTANCES (1 - dot, lower = better) to hybrid_rerank, which treats a larger
+    // vector score as better (bm25.rs:159, sort desc :168) — in hybrid mode the WORST ANN hits rank highest on the vector term.
+    // true (default) reproduces that faithfully; false is the corrected mode: the ANN hits enter the blend as similarities 1 - dist
+    // (BM25-only hits keep the 0.0 of searcher.rs:160-165).  `leann search --compat-polarity true|false`.
+    bool compat_polarity = true;
     SearchOptions(size_t k, size_t c) : top_k(k), complexity(c) {}
     SearchOptions &with_device_filter(std::string key) { device_filter = true; filter_key = std::move(key); return *this; }
     SearchOptions &with_filter(MetadataFilter f) { filter = std::move(f); return *this; }
     SearchOptions &with_hybrid(std::string q, float alpha) { hybrid = true; hybrid_alpha = alpha; query_text = std::move(q); return *this; }
+    SearchOptions &with_compat_polarity(bool on) { compat_polarity = on; return *this; }
 };
 
 inline std::vector<std::string> read_id_map(const std::string &index_path, const PassageStore &passages) {
@@ -536,6 +542,8 @@ class IndexSearcher {
             // The reference re-reads every passage and rebuilds the BM25 tables per query (:149-151, :213-224);
             // the index is immutable while open, so the tables are built once and kept —
             // scores are identical.
+            if (!opts.compat_polarity)
+                for (auto &r : vector_results) r.second = 1.0f - r.second; // corrected polarity (N1): similarity, larger = better
             const Bm25Scorer &scorer = bm25();
             auto bm25_scores = scorer.score_query(*opts.query_text);
             auto bm25_top = scorer.search(*opts.query_text, fetch_k);

@@ -44,6 +44,46 @@ def hybrid_rerank(vector_results, bm25_scores, alpha):
     return out
 
 
+def hybrid_rerank_sparse(vector_results, positives, n_docs, alpha):
+    """hybrid_rerank when the BM25 score vector is given by its non-zero entries: positives = {idx: f32 score}, every other of the
+    n_docs passages scores 0.0.  By definition equal to hybrid_rerank(vector_results, dense, alpha) with dense[idx] = score
+    (tests/test_cpu_searcher.py checks the two against each other); exists so that a 10M-passage check does not fold 10M zeros in Python."""
+    alpha = f32(alpha)
+    max_v, min_v = f32(-np.inf), f32(np.inf)
+    for _, s in vector_results:
+        max_v = max(max_v, f32(s))
+        min_v = min(min_v, f32(s))
+    v_range = max(f32(max_v - min_v), f32(1e-6))
+    max_b, min_b = f32(-np.inf), f32(np.inf)
+    for b in positives.values():
+        max_b = max(max_b, f32(b))
+        min_b = min(min_b, f32(b))
+    if len(positives) < n_docs:  # at least one passage scores 0.0
+        max_b = max(max_b, f32(0.0))
+        min_b = min(min_b, f32(0.0))
+    b_range = max(f32(max_b - min_b), f32(1e-6))
+    out = []
+    with np.errstate(invalid="ignore", over="ignore"):
+        for idx, s in vector_results:
+            norm_vec = f32(f32(f32(s) - min_v) / v_range)
+            bm = f32(positives.get(idx, 0.0)) if idx < n_docs else f32(0.0)
+            norm_b = f32(f32(bm - min_b) / b_range)
+            out.append((idx, f32(f32(alpha * norm_vec) + f32(f32(f32(1.0) - alpha) * norm_b))))
+    out.sort(key=lambda t: -float(t[1]))
+    return out
+
+
+def hybrid_leg_sparse(keys, dists, positives_sorted, n_docs, alpha, top_k, fetch_k, compat_polarity=True):
+    """searcher.rs:146-169 on a backend answer (keys, dists) and BM25 positives [(idx, score)] sorted as Bm25Scorer::search sorts
+    them (score descending, stable): polarity, injection of BM25-only hits of bm25_top with 0.0, rerank, first top_k."""
+    vr = [(int(k), f32(d) if compat_polarity else f32(f32(1.0) - f32(d))) for k, d in zip(keys, dists)]
+    have = {i for i, _ in vr}
+    for idx, _ in positives_sorted[:fetch_k]:
+        if int(idx) not in have:
+            vr.append((int(idx), f32(0.0)))
+    return hybrid_rerank_sparse(vr, {int(i): f32(s) for i, s in positives_sorted}, n_docs, alpha)[:top_k]
+
+
 def _parse_value(s):
     try:
         return int(s)
@@ -127,14 +167,19 @@ def parse_filter(text):
 
 
 def search_with_options(backend_search, id_map, passages, query_embedding, top_k, complexity, filter_text=None, hybrid=False,
-                        hybrid_alpha=0.7, query_text=None):
+                        hybrid_alpha=0.7, query_text=None, compat_polarity=True):
     """backend_search(query, fetch_k, complexity) -> (keys, dists), best first, possibly fewer than fetch_k.
-    passages: {id: {"text": ..., "metadata": {...}}}.  Returns [(id, f32 score)]."""
+    passages: {id: {"text": ..., "metadata": {...}}}.  Returns [(id, f32 score)].
+    compat_polarity=True is the reference as written (N1: the backend's DISTANCES enter hybrid_rerank as if larger were better);
+    False is the corrected pair SURVEY.md N1 asks for: the ANN hits enter the blend as similarities 1 - dist (f32), BM25-only hits
+    still with 0.0 as at searcher.rs:160-165.  Only the hybrid branch is affected."""
     matches = parse_filter(filter_text) if filter_text else None
     fetch_k = top_k * 5 if (matches is not None or hybrid) else top_k
     keys, dists = backend_search(query_embedding, fetch_k, complexity)
     vector_results = [(int(k), f32(d)) for k, d in zip(keys, dists)]
     if hybrid and query_text is not None:
+        if not compat_polarity:
+            vector_results = [(i, f32(f32(1.0) - d)) for i, d in vector_results]
         all_texts = [passages[i]["text"] if i in passages else "" for i in id_map]  # get_all_texts :213-224
         scorer = bo.Bm25Scorer.build(all_texts)
         bm25_scores = scorer.score_query(query_text)

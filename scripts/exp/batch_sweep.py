@@ -16,7 +16,7 @@ ok, od, oc = la.DeviceArray((NQ, k), np.uint64), la.DeviceArray((NQ, k), np.floa
 for nq in (64, 256, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192):
     line = f"nq={nq:5d}:"
     for nw in (4, 8, 16):
-        os.environ["LEANN_DEBUG_NW"] = str(nw)
+        os.environ["LEANN_DEBUG_NW"] = str(nw); L.leann_debug_reload_env()
         s.search_batch_device(Q.ptr, nq, k, ef, ok.ptr, od.ptr, oc.ptr, None, None); la.sync()
         reps = 20 if nq <= 1024 else 8
         t0 = time.perf_counter()

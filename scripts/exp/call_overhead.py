@@ -13,6 +13,7 @@ for d in (128, 768):
     for env in ("0", "1"):
         if env == "1": os.environ["LEANN_DEBUG_NO_ZERO_COPY"] = "1"
         else: os.environ.pop("LEANN_DEBUG_NO_ZERO_COPY", None)
+        la.lib().leann_debug_reload_env()  # the library reads its knobs once
         for _ in range(200): s.search_batch(q, 5, 8)
         t = []
         for _ in range(3000):

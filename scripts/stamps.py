@@ -24,6 +24,7 @@ for nq in (16384, 64):
     ok, od, oc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
     stamps = la.DeviceArray((nq, 8), np.uint64)
     os.environ["LEANN_STAMP_BUF"] = str(stamps.ptr)
+    la.lib().leann_debug_reload_env()  # the library reads its knobs once
     for _ in range(2):
         s.search_batch_device(Q.ptr, nq, k, ef, ok.ptr, od.ptr, oc.ptr, None, None); la.sync()
     st = stamps.to_host().astype(np.float64)

@@ -33,3 +33,13 @@ def gpu(la):
     if la.device_count() < 1:
         pytest.fail("no HIP device visible: -m gpu tests must run on the GPU box")
     return 0
+
+
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment(request):
+    """The library reads its environment knobs once; a test that flips one (monkeypatch.setenv + leann_debug_reload_env) must not leak it
+    into the next test: after the test — and after monkeypatch has restored the environment (autouse fixtures are torn down last) — the
+    knobs are read again."""
+    yield
+    if "la" in request.fixturenames:
+        request.getfixturevalue("la").lib().leann_debug_reload_env()

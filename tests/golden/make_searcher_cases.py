@@ -56,6 +56,12 @@ def main():
              backend=backend(rng, n, 20)),
         dict(name="hybrid_equal_distances", top_k=4, hybrid=True, alpha=0.7, query_text="bm25 ranking",
              backend=[[k, 0.5] for k in (9, 3, 40, 17, 22)]),
+        # corrected polarity (`--compat-polarity false`): ANN hits enter the blend as 1 - dist
+        dict(name="hybrid_corrected_polarity", top_k=5, hybrid=True, alpha=0.7, compat_polarity=False, query_text="diskann vamana prune",
+             backend=backend(rng, n, 25)),
+        dict(name="hybrid_corrected_no_bm25_match", top_k=3, hybrid=True, alpha=0.7, compat_polarity=False, query_text="zzzz qqqq",
+             backend=backend(rng, n, 15)),
+        dict(name="plain_corrected_polarity_is_a_noop", top_k=5, compat_polarity=False, backend=backend(rng, n, 5)),
     ]
     for c in cases:
         rec = c["backend"]
@@ -64,7 +70,8 @@ def main():
             return [k for k, _ in rec], [np.float32(d) for _, d in rec]  # the recorded list (<= fetch_k entries by construction)
         assert len(rec) <= c["top_k"] * (5 if (c.get("filter") or c.get("hybrid")) else 1)
         res = so.search_with_options(bsearch, id_map, passages, None, c["top_k"], 64, filter_text=c.get("filter"),
-                                     hybrid=c.get("hybrid", False), hybrid_alpha=c.get("alpha", 0.7), query_text=c.get("query_text"))
+                                     hybrid=c.get("hybrid", False), hybrid_alpha=c.get("alpha", 0.7), query_text=c.get("query_text"),
+                                     compat_polarity=c.get("compat_polarity", True))
         c["expect"] = [[i, float(s)] for i, s in res]
     out = dict(corpus=docs, cases=cases)
     with open(os.path.join(ROOT, "tests", "golden", "searcher_cases.json"), "w") as f:

@@ -1,0 +1,69 @@
+"""`python bench.py --gpus N` as the driver invokes it (no launcher around it): bench.py starts the N ranks itself as a child process,
+relays rank 0's JSON line and returns the children's exit code; when the ranks produce no line it tries the one-process composite
+handle.  No GPU needed: the child command is intercepted."""
+import importlib.util
+import os
+import subprocess
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_launch_command_is_one_rank_per_gpu_under_torch_distributed_run():
+    b = _bench()
+    cmd = b.launch_command(8, 29511, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    comp = b.composite_command(["--gpus", "8", "--mode", "shard", "--steps", "3"])
+    assert comp == [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--mode", "composite"]
+
+
+def test_self_launch_relays_the_line_and_falls_back_to_the_composite_handle(capsys):
+    b = _bench()
+    args = types.SimpleNamespace(gpus=4, workload="hnsw100k", mode="shard")
+    seen = []
+
+    def ok(cmd):
+        seen.append(cmd)
+        return types.SimpleNamespace(returncode=0, stdout=b'NCCL banner\n{"n_gpus": 4, "value": 1.0}\n')
+    assert b.self_launch(args, ["--gpus", "4"], run=ok) == 0
+    assert capsys.readouterr().out.strip() == '{"n_gpus": 4, "value": 1.0}'
+    assert len(seen) == 1 and "--nproc-per-node=4" in seen[0]
+
+    seen.clear()
+
+    def ranks_fail(cmd):
+        seen.append(cmd)
+        if "torch.distributed.run" in cmd:
+            return types.SimpleNamespace(returncode=1, stdout=b"")
+        return types.SimpleNamespace(returncode=0, stdout=b'{"n_gpus": 4, "config": {"parallelism": "composite4"}}\n')
+    assert b.self_launch(args, ["--gpus", "4"], run=ranks_fail) == 0
+    assert len(seen) == 2 and seen[1][-2:] == ["--mode", "composite"]
+    assert "composite4" in capsys.readouterr().out
+
+    def all_fail(cmd):
+        return types.SimpleNamespace(returncode=3, stdout=b"")
+    assert b.self_launch(args, ["--gpus", "4"], run=all_fail) == 3
+
+
+def test_gpus_2_without_a_gpu_fails_in_the_child_ranks_not_in_an_argument_check():
+    """here (no GPU) the ranks start, find no device and say so; the parent returns their failure"""
+    env = dict(os.environ, LEANN_BENCH_NO_COMPOSITE_FALLBACK="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "hnsw100k", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode != 0
+    assert "torch.distributed.run" in err  # the spawned command line is logged
+    assert "needs a GPU" in err or "GPUs requested" in err  # said by the ranks
+    assert "must be launched" not in err

@@ -39,7 +39,8 @@ def test_python_restatement_reproduces_the_fixture(po):
         rec = c["backend"]
         res = so.search_with_options(lambda q, fk, cx: ([k for k, _ in rec], [f32(d) for _, d in rec]), id_map, passages, None,
                                      c["top_k"], 64, filter_text=c.get("filter"), hybrid=c.get("hybrid", False),
-                                     hybrid_alpha=c.get("alpha", 0.7), query_text=c.get("query_text"))
+                                     hybrid_alpha=c.get("alpha", 0.7), query_text=c.get("query_text"),
+                                     compat_polarity=c.get("compat_polarity", True))
         assert [(i, f32(s)) for i, s in res] == [(i, f32(s)) for i, s in c["expect"]], c["name"]
 
 
@@ -59,6 +60,40 @@ def test_hybrid_rerank_restatements_agree(po):
         assert [(i, f32(s)) for i, s in a] == [(i, f32(s)) for i, s in b], c["name"]
 
 
+def test_sparse_form_of_hybrid_rerank_equals_the_dense_one(po):
+    """hybrid_rerank_sparse / hybrid_leg_sparse (used where N is 10M: bench.py --hybrid, tests/test_gpu_hybrid.py) == the literal
+    dense restatement, f32 bit for bit, incl. no positives, all passages positive, ties and ANN hits that are BM25 positives"""
+    import searcher_oracle as so
+    rng = np.random.default_rng(77)
+    for trial in range(200):
+        n_docs = int(rng.integers(5, 400))
+        nv = int(rng.integers(0, min(n_docs, 60) + 1))
+        keys = rng.choice(n_docs, size=nv, replace=False)
+        dists = np.sort(rng.uniform(0.0, 1.4, size=nv)).astype(np.float32)
+        npos = n_docs if trial % 9 == 0 else int(rng.integers(0, min(n_docs, 70) + 1))
+        pidx = rng.choice(n_docs, size=npos, replace=False)
+        psc = (rng.integers(1, 30, size=npos) * 0.25).astype(np.float32)
+        dense = np.zeros(n_docs, np.float32)
+        dense[pidx] = psc
+        alpha = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+        vr = [(int(k), f32(d)) for k, d in zip(keys, dists)]
+        a = so.hybrid_rerank(vr, dense, alpha)
+        b = so.hybrid_rerank_sparse(vr, {int(i): f32(s) for i, s in zip(pidx, psc)}, n_docs, alpha)
+        assert [(i, f32(s).tobytes()) for i, s in a] == [(i, f32(s).tobytes()) for i, s in b], trial
+        # the whole leg against bm25_oracle's own ordering rule (score desc, stable by index)
+        order = sorted(range(npos), key=lambda t: (-float(psc[t]), int(pidx[t])))
+        pos_sorted = [(int(pidx[t]), f32(psc[t])) for t in order]
+        fetch_k = 50
+        for compat in (True, False):
+            got = so.hybrid_leg_sparse(keys, dists, pos_sorted, n_docs, alpha, 10, fetch_k, compat)
+            vr2 = [(int(k), f32(d) if compat else f32(f32(1.0) - f32(d))) for k, d in zip(keys, dists)]
+            have = {i for i, _ in vr2}
+            top = [i for i in sorted(range(n_docs), key=lambda i: (-float(dense[i]), i)) if dense[i] > 0][:fetch_k]  # Bm25Scorer::search
+            vr2 += [(i, f32(0.0)) for i in top if i not in have]
+            exp = so.hybrid_rerank(vr2, dense, alpha)[:10]
+            assert [(i, f32(s).tobytes()) for i, s in got] == [(i, f32(s).tobytes()) for i, s in exp], (trial, compat)
+
+
 def test_semantics_the_fixture_pins():
     by = {c["name"]: c for c in FX["cases"]}
     # keys beyond the id map become their decimal string (searcher.rs:180-184); no such passage -> skipped (:203-205)
@@ -71,6 +106,11 @@ def test_semantics_the_fixture_pins():
     c = by["hybrid_no_bm25_match"]
     worst_first = [str(k + 1) for k, _ in sorted(c["backend"], key=lambda t: -t[1])][:3]
     assert [i for i, _ in c["expect"]] == worst_first
+    # ... and the corrected mode (`--compat-polarity false`, 1 - dist into the blend) puts the BEST distance first on the same kind of input
+    c = by["hybrid_corrected_no_bm25_match"]
+    best_first = [str(k + 1) for k, _ in sorted(c["backend"], key=lambda t: t[1])][:3]
+    assert [i for i, _ in c["expect"]] == best_first
+    assert by["plain_corrected_polarity_is_a_noop"]["expect"] == [[str(k + 1), d] for k, d in by["plain_corrected_polarity_is_a_noop"]["backend"]]
 
 
 def test_cpp_assemble_results_matches_the_fixture(tmp_path):

@@ -78,6 +78,7 @@ def test_filtered_vamana_and_hbm_table(la, po, gpu, monkeypatch):
     bm, _ = _bitmap(rng, n, 0.1)
     _same(G, s, Q, 10, 64, bm, algo=1)
     monkeypatch.setenv("LEANN_DEBUG_HASH_BITS", "8")  # every query migrates to the HBM visited table mid-search
+    la.lib().leann_debug_reload_env()
     _same(G, s, Q, 10, 32, bm, algo=1)
     assert s.stats()["n_table_overflow"] == len(Q)
     s.close()

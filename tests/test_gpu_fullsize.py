@@ -144,8 +144,10 @@ def test_fullsize_recompute_properties(la, po, gpu, monkeypatch):
     k5, s5, _ = search(5)
     assert (k5 == gk[:, :5]).all() and (s5.view(np.uint32) == gs[:, :5].view(np.uint32)).all()   # prefix property
     monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")                                                 # same kernel, slab + segment top-k
+    la.lib().leann_debug_reload_env()
     sk, ss, _ = search(k)
     monkeypatch.delenv("LEANN_DEBUG_NO_EMIT")
+    la.lib().leann_debug_reload_env()
     assert (sk == gk).all() and (ss.view(np.uint32) == gs.view(np.uint32)).all()
     # oracle on the winners (rows fetched back from HBM): score = <l2norm(W^T f), q>  (recompute.rs:96-103)
     for i in (0, 17, 63):
@@ -160,8 +162,10 @@ def test_fullsize_recompute_properties(la, po, gpu, monkeypatch):
     dM = la.DeviceArray.from_host(np.packbits(allowed, bitorder="little"))
     lk, ls, lc = search(k, dM)
     monkeypatch.setenv("LEANN_RECOMPUTE_NO_LIST", "1")
+    la.lib().leann_debug_reload_env()
     fk, fs, fc = search(k, dM)
     monkeypatch.delenv("LEANN_RECOMPUTE_NO_LIST")
+    la.lib().leann_debug_reload_env()
     assert (lk == fk).all() and (ls.view(np.uint32) == fs.view(np.uint32)).all() and (lc == fc).all()
     assert allowed[lk.astype(np.int64)].all()
     L.leann_recompute_close(r)

@@ -97,6 +97,44 @@ def test_vamana_search_matches_oracle(la, po, gpu):
     s.close()
 
 
+def test_reference_exact_ef_mode(la, po, gpu, monkeypatch):
+    """the reference's HNSW searcher runs at expansion_search = 64 whatever --complexity says (hnsw.rs:49, :83
+    `_complexity`).  LEANN_HNSW_REFERENCE_EF=1 when the handle is made latches that into an HNSW handle: every complexity gives the
+    oracle's ef = max(64, top_k) answer; a DiskANN handle still honours complexity (diskann.rs:54); a handle made without the
+    variable honours it too."""
+    n, d, M = 4000, 128, 16
+    X = synth(po, n, d, r=0)
+    Q = synth(po, 48, d, stream=1, r=0)
+    G = po.Graph.build_hnsw(X, M=M, efc=64)
+    lv, uo, a0, aU = G.export()
+    plain = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, M, 2 * M, G.max_level, G.entry, lv, uo, a0, aU)
+    monkeypatch.setenv("LEANN_HNSW_REFERENCE_EF", "1")
+    la.lib().leann_debug_reload_env()
+    ref = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, M, 2 * M, G.max_level, G.entry, lv, uo, a0, aU)
+    V = po.Graph.build_vamana(X, R=16, L=48, alpha=1.2)
+    vl, vu, v0, vU = V.export()
+    vam = la.BackendSearcher.from_arrays(la.BackendType.DiskAnn, X, 16, 16, 0, V.entry, vl, vu, v0, vU)
+    monkeypatch.delenv("LEANN_HNSW_REFERENCE_EF")
+    la.lib().leann_debug_reload_env()  # the mode is a property of the handle from here on
+    o64 = G.search_batch(Q, 10, 64, 0, 4)
+    for complexity in (1, 16, 64, 300):
+        gk, gd, _ = ref.search_batch(Q, 10, complexity)
+        assert (gk == o64[0]).all() and (gd == o64[1]).all()
+        k1, d1 = ref.search(Q[7], 10, complexity)
+        assert (k1 == o64[0][7]).all()
+    o100 = G.search_batch(Q, 100, 100, 0, 4)  # top_k above 64 widens the beam (usearch: expansion = max(expansion_search, wanted))
+    gk, gd, _ = ref.search_batch(Q, 100, 5)
+    assert (gk == o100[0]).all()
+    o16 = G.search_batch(Q, 10, 16, 0, 4)
+    gk, _, _ = plain.search_batch(Q, 10, 16)
+    assert (gk == o16[0]).all() and not (o16[0] == o64[0]).all()
+    v16 = V.search_batch(Q, 10, 16, 1, 4)
+    gk, _, _ = vam.search_batch(Q, 10, 16)
+    assert (gk == v16[0]).all()
+    for s in (plain, ref, vam):
+        s.close()
+
+
 def test_duplicates_and_ties(la, po, gpu):
     """Adversarial: every vector appears 4 times -> exact distance ties must resolve to the lower id."""
     base = synth(po, 500, 128)
@@ -132,12 +170,15 @@ def test_visited_table_overflow_moves_to_hbm_pool(la, po, gpu, monkeypatch):
     lv, uo, a0, aU = G.export()
     s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, M, 2 * M, G.max_level, G.entry, lv, uo, a0, aU)
     monkeypatch.setenv("LEANN_DEBUG_HASH_BITS", "8")
+    la.lib().leann_debug_reload_env()
     _assert_same(po, G, s, Q, 10, 16)
     assert s.stats()["n_table_overflow"] == len(Q)
     monkeypatch.setenv("LEANN_DEBUG_HASH_BITS", "11")
+    la.lib().leann_debug_reload_env()
     _assert_same(po, G, s, Q, 10, 64)
     assert 0 < s.stats()["n_table_overflow"] <= len(Q)
     monkeypatch.delenv("LEANN_DEBUG_HASH_BITS")
+    la.lib().leann_debug_reload_env()
     _assert_same(po, G, s, Q, 10, 64)
     assert s.stats()["n_table_overflow"] == 0
     s.close()
@@ -258,12 +299,14 @@ def test_scan_topk_candidate_emission_and_overflow(la, po, gpu, monkeypatch):
     dXs = la.DeviceArray.from_host(X[order])
     ak, as_, ac = run(rows=dXs)
     monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")
+    la.lib().leann_debug_reload_env()
     sk, ss, sc = run()
     assert (sk == gk).all() and (ss.view(np.uint32) == gs.view(np.uint32)).all()
     bk, bs, bc = run(rows=dXs)
     assert (ak == bk).all() and (as_.view(np.uint32) == bs.view(np.uint32)).all()
     assert (ak[0] - 7 >= n - 40).all()  # query 0's winners sit at the very end
     monkeypatch.delenv("LEANN_DEBUG_NO_EMIT")
+    la.lib().leann_debug_reload_env()
     # a deep list (k = 300): the candidate lists are sized with k
     dk, ds, dc = la.DeviceArray((4, 300), np.uint64), la.DeviceArray((4, 300), np.float32), la.DeviceArray(4, np.uint32)
     la._native.check(la.lib().leann_scan_topk_device(dX.ptr, n, d, d, dQ.ptr, 4, 300, None, 0, dk.ptr, ds.ptr, dc.ptr, None))

@@ -250,21 +250,27 @@ def test_multi_chunk_candidate_emission(la, po, gpu, monkeypatch):
     gk, gs, gc = _search(la, r, dQ, nq, k)
     assert (gc == k).all() and (np.diff(gs, axis=1) <= 0).all()
     monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")           # same fused kernel, score slab + segment top-k
+    la.lib().leann_debug_reload_env()
     sk, ss, sc = _search(la, r, dQ, nq, k)
     assert (gk == sk).all() and (gs.view(np.uint32) == ss.view(np.uint32)).all()
     monkeypatch.setenv("LEANN_DEBUG_FUSED_V1", "1")          # general kernel (different accumulation order)
+    la.lib().leann_debug_reload_env()
     vk, vs, vc = _search(la, r, dQ, nq, k)
     assert np.abs(vs - gs).max() <= 1e-5 and (vk == gk).mean() > 0.98
     monkeypatch.delenv("LEANN_DEBUG_NO_EMIT")
+    la.lib().leann_debug_reload_env()
     monkeypatch.delenv("LEANN_DEBUG_FUSED_V1")
+    la.lib().leann_debug_reload_env()
     # a handle without the fragment-major feature copy (row-major loads): the same arithmetic, bit for bit
     monkeypatch.setenv("LEANN_RECOMPUTE_NO_TILED", "1")
+    la.lib().leann_debug_reload_env()
     r2 = C.c_void_p()
     chk(L.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 5000, C.byref(r2)))
     rk, rs, rc = _search(la, r2, dQ, nq, k)
     assert (rk == gk).all() and (rs.view(np.uint32) == gs.view(np.uint32)).all()
     L.leann_recompute_close(r2)
     monkeypatch.delenv("LEANN_RECOMPUTE_NO_TILED")
+    la.lib().leann_debug_reload_env()
     # oracle on the winners: score = <l2norm(W^T f), q>  (recompute.rs:96-103)
     F = dF.to_host()
     for i in (0, 33, 69, 149):
@@ -279,9 +285,11 @@ def test_multi_chunk_candidate_emission(la, po, gpu, monkeypatch):
     mk, ms, mc = _search(la, r, dQ, nq, k, dM)
     assert ((mk - 5000) % 5 == 0).all() and (mc == k).all()
     monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")
+    la.lib().leann_debug_reload_env()
     nk, ns, nc = _search(la, r, dQ, nq, k, dM)
     assert (mk == nk).all() and (ms.view(np.uint32) == ns.view(np.uint32)).all()
     monkeypatch.delenv("LEANN_DEBUG_NO_EMIT")
+    la.lib().leann_debug_reload_env()
     # The early filter (recompute.rs:62-79): a mask that allows at most half of the passages is compacted and only the allowed rows
     # are embedded (fused_fstat_kernel<16, false, true>).  Per-passage arithmetic is unchanged, so the answer equals the masked
     # pass over everything (LEANN_RECOMPUTE_NO_LIST=1) bit for bit — 20 % (emission over a 140k-row list), 0.3 % (slab only),
@@ -296,8 +304,10 @@ def test_multi_chunk_candidate_emission(la, po, gpu, monkeypatch):
         dM = la.DeviceArray.from_host(mask)
         lk, ls, lc = _search(la, r, dQ, nq, k, dM)
         monkeypatch.setenv("LEANN_RECOMPUTE_NO_LIST", "1")
+        la.lib().leann_debug_reload_env()
         fk, fs, fc = _search(la, r, dQ, nq, k, dM)
         monkeypatch.delenv("LEANN_RECOMPUTE_NO_LIST")
+        la.lib().leann_debug_reload_env()
         assert (lc == fc).all() and (lk == fk).all() and (ls.view(np.uint32) == fs.view(np.uint32)).all(), sel
         assert (lc == min(k, int(allowed.sum()))).all()
         live = lk != np.iinfo(np.uint64).max
@@ -323,6 +333,7 @@ def test_candidate_list_overflow_falls_back(la, po, gpu, monkeypatch):
     chk(L.leann_recompute_create(dF.ptr, n, h, dW.ptr, d, 0, 0, C.byref(r)))
     gk, gs, gc = _search(la, r, dQ, nq, k)
     monkeypatch.setenv("LEANN_DEBUG_NO_EMIT", "1")
+    la.lib().leann_debug_reload_env()
     sk, ss, sc = _search(la, r, dQ, nq, k)
     assert (gk == sk).all() and (gs.view(np.uint32) == ss.view(np.uint32)).all()
     assert gk.min() > n - 2000                                             # the winners are at the far end

@@ -173,6 +173,7 @@ def test_waves_per_query_do_not_change_results(la, po, gpu, monkeypatch, nw):
     lv, uo, a0, aU = G.export()
     s = la.BackendSearcher.from_arrays(la.BackendType.Hnsw, X, 16, 32, G.max_level, G.entry, lv, uo, a0, aU)
     monkeypatch.setenv("LEANN_DEBUG_NW", nw)
+    la.lib().leann_debug_reload_env()
     ok, od, oc, ost = G.search_batch(Q, 10, 64, 0, 4)
     s.stats(reset=True)
     gk, gd, gc = s.search_batch(Q, 10, 64)
@@ -259,7 +260,9 @@ def test_visited_set_never_runs_out(la, po, gpu, monkeypatch):
     assert int(ost[:, 0].min()) > 3500  # every query visits far more than a 2^10-slot (or 2^12-slot) table holds
     s.close()
     monkeypatch.setenv("LEANN_DEBUG_HASH_BITS", "8")     # LDS table: 256 slots
+    la.lib().leann_debug_reload_env()
     monkeypatch.setenv("LEANN_DEBUG_GPOOL_BITS", "10")   # pool 1: 1 024 slots -> pool 2 (sized by n)
+    la.lib().leann_debug_reload_env()
     s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, d, M, 32)  # (the pools are sized at first use, per handle)
     s.stats(reset=True)
     gk, gd, gc = s.search_batch(Q, 10, 400)
@@ -270,6 +273,7 @@ def test_visited_set_never_runs_out(la, po, gpu, monkeypatch):
     assert (k1 == ok[7]).all() and (d1 == od[7]).all()
     s.close()
     monkeypatch.setenv("LEANN_DEBUG_GPOOL2_BITS", "12")  # defensive path: even the last level is too small
+    la.lib().leann_debug_reload_env()
     s = la.BackendSearcher.build_device(la.BackendType.Hnsw, dX.ptr, n, d, d, M, 32)
     with pytest.raises(la.LeannError) as e:
         s.search_batch(Q, 10, 400)

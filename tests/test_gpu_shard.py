@@ -98,6 +98,15 @@ def test_sharded_handle_behind_the_c_abi(la, po, gpu, G):
     la.sync()
     for o in outs:
         assert (o[0].to_host() == mk).all() and (o[1].to_host() == md).all() and (o[2].to_host() == mc).all()
+    # d_stats on a composite handle is [nq x 4] as the header documents for every handle (it used to be [G x nq x 4],
+    # a silent overrun of a buffer sized as documented): counters summed over the shards, nothing written past nq x 4
+    guard = np.full((nq + 8, 4), 0xABCD1234, np.uint32)
+    dst = la.DeviceArray.from_host(guard)
+    sh.search_batch_device(dQ.ptr, nq, k, ef, outs[0][0].ptr, outs[0][1].ptr, outs[0][2].ptr, d_stats=dst.ptr)
+    la.sync()
+    got = dst.to_host()
+    assert (got[nq:] == 0xABCD1234).all()
+    assert int(got[:nq, 0].sum()) == evals and (got[:nq, 3] == 0).all()
     # ... and as ONE ordinary backend handle
     s = sh.as_backend()
     assert s.len() == n and s.dims() == d
