@@ -405,6 +405,70 @@ def self_launch(args, argv, run=None):
     return proc.returncode or 1
 
 
+# compact legs of the other 1-GPU BASELINE configs: (name, argv, rough seconds on an MI355X box incl. corpus generation and index build)
+OTHER_CONFIGS = [
+    ("hnsw1m_ef128", ["--workload", "hnsw1m", "--ef", "128", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-latency"], 25),
+    ("recompute10m_exhaustive_batch64", ["--workload", "recompute10m", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"], 40),
+    ("recompute10m_graph", ["--workload", "recompute10m_graph", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-latency",
+                            "--small-batch", "64"], 70),
+    ("vamana10m1536_r32_hybrid", ["--workload", "vamana10m1536_r32", "--hybrid", "--steps", "10", "--warmup", "2", "--no-latency",
+                                  "--cpu-queries", "1024"], 170),
+]
+
+
+def summarise_leg(j):
+    """what `other_configs` keeps of a leg's own JSON line"""
+    r = j.get("roofline", {})
+    o = {"value": j.get("value"), "unit": j.get("unit"), "recall_at_10": j.get("recall_at_10"), "ms_per_step": j.get("ms_per_step"),
+         "steps": j.get("steps"), "workload": j.get("config", {}).get("workload"), "ef_search": j.get("config", {}).get("ef_search"),
+         "index_build_s": j.get("config", {}).get("index_build_s"),
+         "roofline": {"bound": r.get("bound"), "frac": r.get("frac"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit")},
+         "kernel": r.get("kernel"), "kernel_avg_ms": r.get("kernel_avg_ms", r.get("fused_encode_score_ms"))}
+    for key in ("small_batch", "hybrid", "cpu_baseline"):
+        if key in j:
+            o[key] = j[key]
+    return o
+
+
+def run_all_configs(args, argv, run=None):
+    """Default run: the headline workload (a child with --headline-only and the caller's flags), then compact legs of configs[1], [2]
+    and [4] while the time budget lasts (LEANN_BENCH_BUDGET_S, default 420 s), one JSON line in the end: the headline's line plus
+    `other_configs`.  Returns the exit code (the headline's)."""
+    import subprocess
+    me = os.path.abspath(__file__)
+    t_start = time.time()
+    budget = float(os.environ.get("LEANN_BENCH_BUDGET_S", "420"))
+    run = run or (lambda cmd: subprocess.run(cmd, stdout=subprocess.PIPE))
+
+    def leg(cmd):
+        p = run(cmd)
+        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        return p.returncode, (json.loads(lines[-1]) if lines else None)
+
+    rc, head = leg([sys.executable, me] + list(argv) + ["--headline-only"])
+    if rc != 0 or head is None:
+        return rc or 1
+    others = {}
+    for name, extra, est in OTHER_CONFIGS:
+        if os.environ.get("LEANN_BENCH_SKIP_OTHERS"):
+            break
+        if time.time() - t_start + est > budget:
+            others[name] = {"skipped": f"time budget ({budget:.0f} s for the whole default run; this leg needs ~{est} s): run `python bench.py {' '.join(extra)}`"}
+            continue
+        t0 = time.time()
+        print(f"[bench] other config {name}: {' '.join(extra)}", file=sys.stderr, flush=True)
+        rc2, j = leg([sys.executable, me] + extra)
+        others[name] = summarise_leg(j) if (rc2 == 0 and j) else {"failed": f"exit code {rc2}"}
+        others[name]["leg_wall_s"] = round(time.time() - t0, 1)
+        others[name]["command"] = "python bench.py " + " ".join(extra)
+    head["other_configs"] = others
+    head["other_configs_note"] = ("compact legs of the other 1-GPU BASELINE configs, each its own process after the headline (same contract: inputs "
+                                  "resident in HBM, barrier-free single-GPU timing of exactly `steps` steps); --headline-only skips them")
+    sys.stdout.write(json.dumps(head) + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -426,12 +490,30 @@ def main():
     ap.add_argument("--filter-selectivity", type=float, default=0.0,
                     help="side experiment (not the headline metric): metadata-filtered search with a seeded random allow-bitmap "
                          "of this density evaluated inside the traversal; recall is measured against the exact FILTERED top-k")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the workload itself.  Without it (and without --workload) the default run measures the headline AND compact legs "
+                         "of every other 1-GPU BASELINE config, each in a child process, and reports them under `other_configs` of the one line")
+    ap.add_argument("--small-batch", type=int, default=0,
+                    help="graph workloads: also time calls of this many queries (BASELINE configs[2] names batch-64) on the same index -> `small_batch`")
+    ap.add_argument("--hybrid", action="store_true",
+                    help="BASELINE configs[4] as a whole (graph workloads): every step searches with fetch_k = 5 k (searcher.rs:129-133), injects "
+                         "the BM25-only hits of a seeded sparse BM25 score vector per query (searcher.rs:154-165) and runs hybrid_rerank "
+                         "(bm25.rs:135-170) on the device (csrc/hybrid.hip), inside the timed region; a >= 1000-query sample of the reranked "
+                         "(id, score) lists is compared with oracle/searcher_oracle.py")
+    ap.add_argument("--hybrid-alpha", type=float, default=0.7, help="weight of the vector term (searcher.rs:47)")
+    ap.add_argument("--compat-polarity", default="true", choices=["true", "false"],
+                    help="true: the reference's blend of DISTANCES (SURVEY.md N1); false: corrected, 1 - dist")
     ap.add_argument("--efc", type=int, default=0, help="override the workload's ef_construction (graph build quality; 0 = the workload's value)")
     ap.add_argument("--filter-exact", action="store_true",
                     help="with --filter-selectivity: answer the filtered queries exactly (allowed rows compacted + f32 MFMA scan, "
                          "leann_backend_search_filtered_exact_batch_device) instead of walking the graph")
     args = ap.parse_args()
 
+    explicit_workload = any(x == "--workload" or x.startswith("--workload=") for x in sys.argv[1:])
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not explicit_workload and not args.headline_only:
+        # the driver's command shape (`python bench.py --gpus 1 --steps K --warmup W`): headline + every other 1-GPU BASELINE config.
+        # This parent never touches the GPU; every leg is a child process of its own.
+        sys.exit(run_all_configs(args, sys.argv[1:]))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.mode != "composite":
         # `python bench.py --gpus N` without a launcher (the driver's command shape): this process has not touched the GPU yet, so
         # it starts the N ranks itself as a CHILD process and relays rank 0's JSON line
@@ -447,7 +529,7 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists in the product path)")
     gloo_rehearsal = os.environ.get("LEANN_BENCH_DIST_BACKEND") == "gloo"
-    if torch.cuda.device_count() < args.gpus and not gloo_rehearsal:
+    if torch.cuda.device_count() < args.gpus and not gloo_rehearsal and not (args.mode == "composite" and os.environ.get("LEANN_BENCH_COMPOSITE_DEVICES")):
         sys.exit(f"bench.py: {args.gpus} GPUs requested, {torch.cuda.device_count()} visible (rank {rank})")
     if torch.cuda.device_count() < world and gloo_rehearsal:
         local_rank = 0  # rehearsal of the N > 1 path on a one-GPU box: ranks share device 0, exchange over gloo
@@ -503,8 +585,11 @@ def main():
         # behind one composite leann_backend handle whose searches fan out, peer-copy the per-shard lists to device 0 and merge there
         from leann_rs_amd.backend import ShardedIndex
         subs = []
+        # (LEANN_BENCH_COMPOSITE_DEVICES="0,0": rehearsal of this path on a one-GPU box — several shards on one device)
+        devs = [int(x) for x in os.environ.get("LEANN_BENCH_COMPOSITE_DEVICES", ",".join(str(g) for g in range(G))).split(",")]
+        assert len(devs) == G, "LEANN_BENCH_COMPOSITE_DEVICES must name one device per shard"
         for g in range(G):
-            dg = torch.device("cuda", g)
+            dg = torch.device("cuda", devs[g])
             with torch.cuda.device(dg):
                 if rgraph:
                     hfeat = wl["h"]
@@ -514,7 +599,7 @@ def main():
                     chk(L.leann_synth_weights_device(SEED, hfeat, d, Wg.data_ptr(), None))
                     torch.cuda.synchronize(dg)
                     rcg = C.c_void_p()
-                    chk(L.leann_recompute_create(Fg.data_ptr(), rows, hfeat, Wg.data_ptr(), d, g, g * rows, C.byref(rcg)))
+                    chk(L.leann_recompute_create(Fg.data_ptr(), rows, hfeat, Wg.data_ptr(), d, devs[g], g * rows, C.byref(rcg)))
                     keep += [Fg, Wg, rcg]
                     if g == 0:
                         F, Wt, rc_h = Fg, Wg, rcg
@@ -532,7 +617,7 @@ def main():
                 subs.append(la.BackendSearcher(hb, backend))
             searcher = ShardedIndex.from_searchers(subs, take_ownership=True).as_backend(backend)
         else:
-            searcher = ShardedIndex.build_device(backend, [x.data_ptr() for x in Xs], [rows] * G, d, ld, M, efc, list(range(G)),
+            searcher = ShardedIndex.build_device(backend, [x.data_ptr() for x in Xs], [rows] * G, d, ld, M, efc, devs,
                                                  keep=tuple(Xs)).as_backend(backend)
         X = Xs[0] if Xs else None
         torch.cuda.set_device(0)
@@ -582,8 +667,18 @@ def main():
             chk(L.leann_synth_rows_device(SEED, d, ld, GEN_R, GEN_CLUSTERS, GEN_SIGMA, 1, q_first, n_pool * B, Q.data_ptr(), sp))
     # two sets of result buffers: with N > 1 the library runs the exchange + merge of step i on its own stream while the
     # traversal of step i + 1 fills the other set (the all-gather is latency-bound, so it is overlapped)
-    kbuf = [torch.empty((B, k), dtype=torch.int64, device=dev) for _ in range(2)]
-    dbuf = [torch.empty((B, k), dtype=torch.float32, device=dev) for _ in range(2)]
+    hybrid = bool(args.hybrid)
+    kk = 5 * k if hybrid else k  # hybrid: fetch_k = 5 * top_k (searcher.rs:129-133)
+    compat = args.compat_polarity == "true"
+    BM_P = 64  # BM25 positives per query (a BM25 score vector is zero except for passages sharing a term with the query)
+    kbuf = [torch.empty((B, kk), dtype=torch.int64, device=dev) for _ in range(2)]
+    dbuf = [torch.empty((B, kk), dtype=torch.float32, device=dev) for _ in range(2)]
+    hyb = None
+    if hybrid:
+        if shard or composite:
+            sys.exit("bench.py --hybrid: single-GPU leg (configs[4] names 1 x MI355X)")
+        hyb = dict(keys=torch.empty((B, k), dtype=torch.int64, device=dev), scores=torch.empty((B, k), dtype=torch.float32, device=dev),
+                   counts=torch.empty((B,), dtype=torch.int32, device=dev), pos=None, sc=None, cnt=None, ms=[])
     cbuf = [torch.empty((B,), dtype=torch.int32, device=dev) for _ in range(2)]
     keys, dists, counts = kbuf[0], dbuf[0], cbuf[0]
     xstream = torch.cuda.Stream(device=dev)
@@ -646,10 +741,16 @@ def main():
             searcher.search_filtered_batch_device(qptr, B, k, ef, allow.data_ptr(), 0, keys.data_ptr(), dists.data_ptr(),
                                                   counts.data_ptr(), stats.data_ptr() + qb * B * 16, sp)
         else:
-            searcher.search_batch_device(qptr, B, k, ef, keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
+            searcher.search_batch_device(qptr, B, kk, ef, keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
                                          stats.data_ptr() + qb * B * 16, sp)
         if timed_events is not None:
             timed_events[1].record(stream)  # (the traversal is queued on `stream`; exchange + merge are not inside this bracket)
+        if hybrid and hyb["pos"] is not None:  # injection of BM25-only hits + hybrid_rerank, on the device, same stream
+            chk(L.leann_hybrid_rerank_device(keys.data_ptr(), dists.data_ptr(), counts.data_ptr(), B, kk, hyb["pos"][qb].data_ptr(),
+                                             hyb["sc"][qb].data_ptr(), hyb["cnt"][qb].data_ptr(), BM_P, corpus_total, args.hybrid_alpha,
+                                             1 if compat else 0, k, hyb["keys"].data_ptr(), hyb["scores"].data_ptr(), hyb["counts"].data_ptr(), sp))
+            if timed_events is not None and len(timed_events) > 2:
+                timed_events[2].record(stream)
         if shard and not rccl:
             # rehearsal without one GPU per rank (LEANN_BENCH_DIST_BACKEND=gloo): torch all-gather + the HIP merge kernel
             ev_search[b].record(stream)
@@ -679,7 +780,7 @@ def main():
     if composite:  # per-device exact lists (scores descending), gathered on device 0 and merged there
         parts = []
         for g in range(G):
-            dg = torch.device("cuda", g)
+            dg = torch.device("cuda", devs[g])
             with torch.cuda.device(dg):
                 Qg = Q[:nrq].to(dg)
                 pk, ps, pc = (torch.empty((nrq, k), dtype=torch.int64, device=dg), torch.empty((nrq, k), dtype=torch.float32, device=dg),
@@ -714,7 +815,7 @@ def main():
     def measure_recall(lo_q, hi_q):
         found = search(0)
         drain()
-        got = found[lo_q:hi_q].cpu().numpy()
+        got = found[lo_q:hi_q, :k].cpu().numpy()  # (hybrid: the first k of the fetch_k ANN hits — recall of the ANN stage)
         return float(np.mean([len(set(got[i].tolist()) & set(truth[lo_q + i].tolist())) / k for i in range(hi_q - lo_q)]))
 
     # "QPS @ recall@10 >= 0.95": the cheapest beam that still meets the bar is picked on the FIRST half of the recall queries and the
@@ -733,11 +834,40 @@ def main():
         recall, bumped = measure_recall(half, nrq), True
     log(f"recall@{k} = {recall:.4f} at ef={ef} (recall queries [{half}, {nrq}), corpus {corpus_total} x {d})" + (" [ef raised after the report-half check]" if bumped else ""))
 
+    if hybrid:
+        # Synthetic BM25 side ("synthetic BM25 score vector, seeded sparse positives"), resident in HBM before the
+        # timed region as the output of the host's persistent Bm25Scorer would be: per query BM_P positives — 16 of them ANN hits of that
+        # query (ranks 2, 5, 8, ...: a passage that matches lexically AND semantically), 48 elsewhere in the corpus — with quantised
+        # scores (ties), sorted by (score desc, position asc) like Bm25Scorer::search (bm25.rs:109-122).
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x5EED0006)
+        stride_ = max(1, corpus_total // 97)
+        P_, S_, C_ = [], [], []
+        for qb in range(n_pool):
+            found = search(qb * 1)  # pool batch qb (step % n_pool == qb for the first n_pool steps)
+            drain()
+            ann = found[:, 2:2 + 3 * 16:3].clone()  # [B, 16] positions from the ANN list
+            base = torch.randint(0, corpus_total, (B, 1), device=dev, generator=gen, dtype=torch.int64)
+            rnd = (base + torch.arange(1, 49, device=dev, dtype=torch.int64)[None, :] * stride_) % corpus_total
+            pos = torch.cat([ann, rnd], 1)
+            sc = (torch.randint(1, 49, (B, BM_P), device=dev, generator=gen).to(torch.float32) * 0.25)
+            sc = torch.where(pos < 0, torch.full_like(sc, -1.0), sc)  # short ANN lists carry key -1 (UINT64_MAX): not a passage
+            pos, o = torch.sort(pos, dim=1, stable=True)             # duplicates adjacent ...
+            sc = torch.gather(sc, 1, o)
+            dup = torch.zeros_like(pos, dtype=torch.bool)
+            dup[:, 1:] = pos[:, 1:] == pos[:, :-1]
+            sc = torch.where(dup, torch.full_like(sc, -1.0), sc)     # ... and dropped
+            sc, o = torch.sort(sc, dim=1, descending=True, stable=True)  # score desc, ties keep position asc
+            pos = torch.gather(pos, 1, o)
+            P_.append(pos.to(torch.int32).contiguous()); S_.append(sc.contiguous()); C_.append((sc > 0).sum(1).to(torch.int32).contiguous())
+        hyb["pos"], hyb["sc"], hyb["cnt"] = P_, S_, C_
+        torch.cuda.synchronize()
+
     # ---- warmup, then exactly K timed steps between barrier + synchronize -------------------------
     for w in range(args.warmup):
         search(w)
     drain()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3 if hybrid else 2)) for _ in range(args.steps)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -778,7 +908,7 @@ def main():
         replica_qps = B * args.steps * world / float(t2.item())
 
     # ---- roofline of the dominant kernel (beam_search_kernel): algorithmic bytes / HIP-event time --
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = [e[0].elapsed_time(e[1]) for e in ev]
     kern_avg_s = float(np.mean(kern_ms)) * 1e-3
     st = stats.cpu().numpy().astype(np.int64)  # every pool batch was searched at least once (steps >= n_pool or fewer batches)
     used = min(n_pool, max(args.steps, 1 + args.warmup))
@@ -885,6 +1015,36 @@ def main():
                                         + (" — ef then raised until the reported half reached 0.95" if bumped else "") if half else
                                         f"fixed ef; recall on {nrq} queries")
 
+    if args.small_batch and n_gpus == 1 and allow is None:
+        # the batch BASELINE configs[2] names (64 queries per call): a latency regime — one workgroup of 16 waves per query walking its
+        # dependent hops, most of the chip idle — reported beside the throughput batch so that neither figure is mistaken for the other
+        sb, reps = min(args.small_batch, B), 200
+        for _ in range(20):
+            searcher.search_batch_device(Q.data_ptr(), sb, kk, ef, kbuf[0].data_ptr(), dbuf[0].data_ptr(), cbuf[0].data_ptr(), None, sp)
+        stream.synchronize()
+        t0 = time.perf_counter()
+        for r_ in range(reps):
+            searcher.search_batch_device(Q.data_ptr() + (r_ % max(1, (n_pool * B) // sb)) * sb * ld * 4, sb, kk, ef, kbuf[0].data_ptr(),
+                                         dbuf[0].data_ptr(), cbuf[0].data_ptr(), None, sp)
+        stream.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out["small_batch"] = {"batch": sb, "ms_per_call": dt * 1e3, "value": sb / dt, "unit": "queries/s",
+                              "hbm_frac": bytes_per_query * sb / dt / 1e9 / HBM_PEAK_GBS,
+                              "note": f"{reps} back-to-back device calls of {sb} queries (latency form of the hop loop, 16 waves per query): "
+                                      "a latency regime, not a bandwidth one"}
+    if hybrid:
+        rr_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        out["hybrid"] = {"fetch_k": kk, "alpha": args.hybrid_alpha, "compat_polarity": compat,
+                         "polarity_note": ("reference as written: backend DISTANCES enter hybrid_rerank as if larger were better (SURVEY.md N1)" if compat
+                                           else "corrected: 1 - dist enters the blend"),
+                         "bm25": f"synthetic, resident in HBM: {BM_P} positives per query (16 of them ANN hits), quantised scores, sorted like Bm25Scorer::search",
+                         "rerank_ran_on": "device (csrc/hybrid.hip:hybrid_rerank_kernel, one workgroup per query), inside the timed region",
+                         "rerank_avg_ms": rr_ms, "traversal_avg_ms": kern_avg_s * 1e3,
+                         "reference": "src/index/searcher.rs:129-169 + src/index/bm25.rs:135-170"}
+        out["config"]["workload"] += f"; HYBRID: fetch_k={kk}, BM25 injection + hybrid_rerank(alpha={args.hybrid_alpha}) on the device per step"
+        out["config"]["top_k"] = k
+        out["recall_note"] = f"recall@{k} of the ANN stage (first {k} of the {kk} fetched) against the exact scan; the reranked order is BM25-blended by design"
+
     # ---- PCIe-inclusive rate: the same batch through the host-pointer entry point (queries and results in host memory) ----
     if n_gpus == 1 and rank == 0 and allow is None and not rgraph:
         try:
@@ -973,19 +1133,68 @@ def main():
                 Qh = Q[:ncpu, :d].contiguous().cpu().numpy()
             log(f"graph + rows copied to host in {time.time() - t0:.1f}s")
             cores = host_cores()
-            G.search_batch(Qh[: min(256, ncpu)], k, ef, 0, cores)  # touch
+            G.search_batch(Qh[: min(256, ncpu)], kk, ef, 0, cores)  # touch
             t0 = time.perf_counter()
-            ck, cd, cc, cs = G.search_batch(Qh, k, ef, 0, cores)
+            ck, cd, cc, cs = G.search_batch(Qh, kk, ef, 0, cores)
             cpu_s = time.perf_counter() - t0
             search(0)
             stream.synchronize()
             gk_ = keys[:ncpu].cpu().numpy().view(np.uint64)
             gd_ = dists[:ncpu].cpu().numpy()
             same = bool((gk_ == ck).all() and (gd_.view(np.uint32) == cd.view(np.uint32)).all())
+            rerank_note = ""
+            if hybrid:
+                # the reference's rerank on the host, per query: injection + hybrid_rerank over a DENSE N-long BM25 vector (its min / max
+                # fold runs over all N scores, bm25.rs:152-154) — oracle/oracle.c:orc_hybrid_rerank, one query per thread
+                from concurrent.futures import ThreadPoolExecutor
+                import threading
+                import searcher_oracle as so
+                pp = hyb["pos"][0][:ncpu].cpu().numpy().view(np.uint32)
+                ps = hyb["sc"][0][:ncpu].cpu().numpy()
+                pc = hyb["cnt"][0][:ncpu].cpu().numpy()
+                tls = threading.local()
+
+                def cpu_rerank(q):
+                    if not hasattr(tls, "dense"):
+                        tls.dense = np.zeros(corpus_total, np.float32)
+                    n_, c_ = int(cc[q]), int(pc[q])
+                    vr = [(int(a_), float(d_) if compat else float(np.float32(1.0) - d_)) for a_, d_ in zip(ck[q, :n_], cd[q, :n_])]
+                    have = {i for i, _ in vr}
+                    vr += [(int(p_), 0.0) for p_ in pp[q, :min(c_, kk)] if int(p_) not in have]
+                    tls.dense[pp[q, :c_]] = ps[q, :c_]
+                    r_ = po.hybrid_rerank(vr, tls.dense, args.hybrid_alpha)[:k]
+                    tls.dense[pp[q, :c_]] = 0.0
+                    return r_
+                nrr = min(ncpu, 2048)
+                with ThreadPoolExecutor(cores) as ex:
+                    list(ex.map(cpu_rerank, range(min(64, nrr))))
+                    t0 = time.perf_counter()
+                    cpu_rr = list(ex.map(cpu_rerank, range(nrr)))
+                    rr_s = (time.perf_counter() - t0) * ncpu / nrr
+                cpu_s += rr_s
+                rerank_note = f" + hybrid rerank per query over a dense {corpus_total}-long BM25 vector ({rr_s / ncpu * 1e3 * cores:.2f} ms per query and thread)"
+                # parity of the DEVICE rerank: (id, f32 score) lists of a >= 1000-query sample against oracle/searcher_oracle.py
+                nsmp = min(ncpu, 1024)
+                hk_ = hyb["keys"][:nsmp].cpu().numpy().view(np.uint64)
+                hs_ = hyb["scores"][:nsmp].cpu().numpy()
+                hc_ = hyb["counts"][:nsmp].cpu().numpy()
+                bad = 0
+                for q in range(nsmp):
+                    exp = so.hybrid_leg_sparse(ck[q, :cc[q]], cd[q, :cc[q]], list(zip(pp[q, :pc[q]].tolist(), ps[q, :pc[q]])), corpus_total,
+                                               args.hybrid_alpha, k, kk, compat)
+                    ok_ = (hc_[q] == len(exp) and [int(x) for x in hk_[q, :hc_[q]]] == [i for i, _ in exp] and
+                           (hs_[q, :hc_[q]].view(np.uint32) == np.array([x for _, x in exp], np.float32).view(np.uint32)).all())
+                    bad += 0 if ok_ else 1
+                out["hybrid"]["rerank_parity"] = {"sample": nsmp, "mismatching_queries": bad,
+                                                  "against": "oracle/searcher_oracle.py:hybrid_leg_sparse on the oracle's own walk of the same graph (ids and f32 score bits)"}
+                # the C port and the numpy restatement must agree too (two restatements of bm25.rs:135-170)
+                out["hybrid"]["cpu_port_equals_numpy_restatement"] = all(
+                    [i for i, _ in cpu_rr[q]] == [i for i, _ in so.hybrid_leg_sparse(ck[q, :cc[q]], cd[q, :cc[q]], list(zip(pp[q, :pc[q]].tolist(), ps[q, :pc[q]])),
+                                                                                       corpus_total, args.hybrid_alpha, k, kk, compat)] for q in range(min(nrr, 256)))
             out["cpu_baseline"] = {
                 "value": ncpu / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
-                "sample": f"{ncpu} queries of the timed batch, same graph + vectors copied from HBM, ef={ef}, k={k}, "
-                          f"one query per thread on {cores} host threads (oracle/oracle.c, AVX2 canonical dot)",
+                "sample": f"{ncpu} queries of the timed batch, same graph + vectors copied from HBM, ef={ef}, k={kk}, "
+                          f"one query per thread on {cores} host threads (oracle/oracle.c, AVX2 canonical dot)" + rerank_note,
                 "gpu_results_bit_identical_on_sample": same,
             }
             if lat is not None:  # the CPU port's latency for ONE query on ONE thread, beside the GPU's single-query latency

@@ -237,6 +237,12 @@ int leann_recompute_create_host(const uint16_t *features, size_t n, size_t h, co
                                 size_t dims, int device, uint64_t key_offset, leann_recompute **out);
 int leann_recompute_search_batch(const leann_recompute *r, const float *queries, size_t nq, size_t top_k,
                                  const uint8_t *allow_mask, uint64_t *keys, float *scores, uint32_t *counts);
+/* Sharded form: `parts` cover consecutive position ranges (part g's key_offset = part g-1's key_offset + its length,
+ * a multiple of 8 past the first part's) and may sit on different devices; a search runs every part's fused scan concurrently and
+ * merges the per-part lists by (score descending, key ascending) — bit for bit the answer of one handle over all passages.  The
+ * queries, the allow mask (over ALL positions, first part's first position = bit 0) and the results live on the first part's
+ * device.  The parts are borrowed: close the composite handle first.  encode / build_index apply to the parts. */
+int leann_recompute_create_sharded(const leann_recompute *const *parts, size_t n_parts, leann_recompute **out);
 /* materialise embeddings of rows [row0, row0+rows) into d_out [rows x ceil4(dims)] (validation) */
 int leann_recompute_encode_device(const leann_recompute *r, uint64_t row0, uint64_t rows, float *d_out,
                                   void *stream);
@@ -283,8 +289,11 @@ int leann_hybrid_rerank_device(const uint64_t *d_keys, const float *d_dists, con
 /* ---- sharded indexes (the reference has no counterpart: IndexSearcher owns one Box<dyn BackendSearcher>,
  * src/index/searcher.rs:68) --------------------------------------------------------------------------------------------------
  * One process, G devices: the composite handle leann_backend_open returns for a device list, or built here from rows / handles.
- * Every leann_backend_search* entry point works on it (the in-traversal allow-bitmap too; exact / registered filters, graph
- * export and save do not).  Queries and results of the *_device calls live on the first device of the list.
+ * Every leann_backend_search* entry point works on it: the in-traversal allow-bitmap, exact filtered search and registered filters
+ * (the bitmap is sliced per shard — interior shard boundaries are multiples of 64 —, every shard answers for its slice, lists are merged
+ * by (dist, key): the same answer as an unsharded index gives for exact searches).  leann_backend_save writes one self-contained file
+ * per shard, "<stem>.shard<g>of<G>.index" / ".diskann", which leann_backend_open with a list of G devices loads again; graph export is
+ * per shard (leann_backend_shard).  Queries and results of the *_device calls live on the first device of the list.
  * One process per GPU: leann_sharded_attach joins this rank's shard to an RCCL communicator (librccl.so is resolved at run time);
  * a search is the local traversal + ONE ncclAllGather of the packed per-shard block {u64 keys | f32 dists | u32 counts} + the merge
  * kernel on every rank.  All ranks must issue the same calls with the same nq / top_k.
@@ -292,6 +301,10 @@ int leann_hybrid_rerank_device(const uint64_t *d_keys, const float *d_dists, con
  * i's exchange (two result slots rotate: wait for ticket t before issuing t + 2). */
 typedef struct leann_sharded leann_sharded;
 int leann_sharded_open(const char *index_path_stem, int backend, size_t dims, const char *device_spec, leann_sharded **out);
+/* the sub-index of shard g of a composite handle as an ordinary handle (borrowed — do not close it; it returns global keys):
+ * graph_info / graph_export / feature_rows_export work on it.  leann_backend_shard_count: 0 for a plain handle. */
+size_t leann_backend_shard_count(const leann_backend *h);
+int leann_backend_shard(const leann_backend *h, size_t g, leann_backend **out);
 /* d_vectors[g]: rows of shard g on devices[g] ([rows[g] x ld] f32, borrowed); keys are rebased by the prefix sums of rows[] */
 int leann_sharded_build_device(int backend, const float *const *d_vectors, const size_t *rows, size_t n_shards, size_t dims,
                                size_t ld, size_t graph_degree, size_t complexity, const int *devices, leann_sharded **out);

@@ -33,6 +33,8 @@ SIGNATURES = {
     "leann_last_error": (C.c_char_p, []),
     "leann_version": (C.c_char_p, []),
     "leann_debug_reload_env": (None, []),
+    "leann_backend_shard_count": (C.c_size_t, [vp]),
+    "leann_backend_shard": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "leann_hybrid_rerank_device": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int,
                                             C.c_size_t, vp, vp, vp, vp]),
     "leann_backend_open": (C.c_int, [C.c_char_p, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(vp)]),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "leann_recompute_create": (C.c_int, [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(vp)]),
     "leann_recompute_create_pooled": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_uint64,
                                                C.POINTER(vp)]),
+    "leann_recompute_create_sharded": (C.c_int, [C.POINTER(vp), C.c_size_t, C.POINTER(vp)]),
     "leann_recompute_create_host": (C.c_int, [C.POINTER(C.c_uint16), C.c_size_t, C.c_size_t, C.POINTER(C.c_uint16), C.c_size_t, C.c_int,
                                              C.c_uint64, C.POINTER(vp)]),
     "leann_recompute_search_batch": (C.c_int, [vp, f32p, C.c_size_t, C.c_size_t, u8p, u64p, f32p, u32p]),

@@ -236,6 +236,18 @@ class BackendSearcher:
         return dict(gi, levels=levels, upper_off=upper_off, adj0=adj0, adjU=adjU[: gi["n_upper_lists"]],
                     vectors=X)
 
+    def n_shards(self):
+        """0 for a plain handle; G for a composite (sharded) one"""
+        return int(N.lib().leann_backend_shard_count(self._h))
+
+    def shard(self, g):
+        """the sub-index of shard g as an ordinary searcher (borrowed: valid while this handle lives; never closed by itself)"""
+        h = C.c_void_p()
+        N.check(N.lib().leann_backend_shard(self._h, g, C.byref(h)))
+        s = BackendSearcher(h, self.backend_type)
+        s._borrowed = True
+        return s
+
     def device_rows_ptr(self):
         return N.lib().leann_backend_device_rows(self._h)
 
@@ -244,7 +256,8 @@ class BackendSearcher:
 
     def close(self):
         if self._h:
-            N.lib().leann_backend_close(self._h)
+            if not getattr(self, "_borrowed", False):
+                N.lib().leann_backend_close(self._h)
             self._h = None
 
     def __del__(self):

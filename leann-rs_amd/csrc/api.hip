@@ -216,7 +216,7 @@ extern "C" const float *leann_backend_device_rows(const leann_backend *h) { retu
 #define NOT_ON_SHARDED(h, what)                                                                                                    \
     do {                                                                                                                           \
         if ((h) && (h)->sharded) {                                                                                                 \
-            leann_set_error("%s is not available on a sharded handle (use the shard handles, or a single-device index)", what);  \
+            leann_set_error("%s is not available on a sharded handle (use leann_backend_shard(h, g) for one shard's)", what);       \
             return LEANN_ERR_UNSUPPORTED;                                                                                          \
         }                                                                                                                          \
     } while (0)
@@ -409,9 +409,11 @@ extern "C" int leann_backend_search_filtered_batch_device(const leann_backend *h
         HIP_CHECK_RET(hipMemsetAsync(d_counts, 0, nq * 4, st));
         return LEANN_OK;
     }
-    if (h->sharded) // composite handle: fan out, gather, merge (shard.hip); d_stats stays [nq x 4]: summed over the shards
-        return leann_internal_sharded_search(h->sharded, d_queries, nq, top_k, complexity, d_allow, allow_stride, d_keys, d_dists, d_counts,
-                                             d_stats, st, nullptr);
+    if (h->sharded) { // composite handle: fan out, gather, merge (shard.hip); d_stats stays [nq x 4]: summed over the shards
+        ShardFilterArgs fa;
+        fa.d_allow = d_allow; fa.allow_stride = allow_stride;
+        return leann_internal_sharded_search(h->sharded, d_queries, nq, top_k, complexity, fa, d_keys, d_dists, d_counts, d_stats, st, nullptr);
+    }
     SearchArgs a{};
     a.queries = d_queries;
     a.ldq = h->g.d;
@@ -442,22 +444,12 @@ extern "C" int leann_backend_search_batch(const leann_backend *hc, const float *
 }
 
 // ... with an optional allow-bitmap over positions (host memory; one shared bitmap when allow_stride == 0)
-// A filter registered on the device (leann_backend_filter_create): the bitmap, the ascending list of allowed positions and its length.
-struct leann_filter {
-    int device = 0;
-    size_t n = 0, n_allowed = 0;
-    uint8_t *d_allow = nullptr;
-    uint32_t *d_list = nullptr; // scratch-pool block (scan.hip), held for the filter's lifetime
-};
 enum { FILTER_WALK = 0, FILTER_EXACT = 1, FILTER_AUTO = 2 };
 static int search_filtered_batch_host(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
                                       const uint8_t *allow, size_t allow_stride, uint64_t *keys, float *dists, uint32_t *counts, int mode,
                                       const leann_filter *flt = nullptr);
 int leann_internal_compact_allow(const uint8_t *d_allow, size_t n, uint32_t **d_list, size_t *n_list, hipStream_t st);
 void leann_internal_scratch_release(void *p);
-int leann_internal_filtered_exact_list(const float *d_rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t top_k,
-                                       const uint32_t *d_list, size_t m, uint64_t key_offset, uint64_t *d_keys, float *d_dists,
-                                       uint32_t *d_counts, hipStream_t st);
 
 // Registered filters: a server that answers many queries under the same metadata filter uploads and compacts the bitmap once
 // (the host-pointer calls above re-send N/8 bytes and re-compact them for every query: 1.25 MB at 10M rows).
@@ -467,7 +459,25 @@ extern "C" int leann_backend_filter_create(const leann_backend *hc, const uint8_
         return LEANN_ERR_INVALID;
     }
     *out = nullptr;
-    NOT_ON_SHARDED(hc, "a registered filter");
+    if (hc->sharded) { // composite handle: one sub-filter per shard — its slice of the bitmap (shard boundaries are multiples of 64), on its device
+        const size_t G = leann_internal_sharded_count(hc->sharded);
+        leann_filter *f = new leann_filter();
+        f->device = hc->device;
+        f->n = hc->g.n;
+        for (size_t g = 0; g < G; g++) {
+            leann_backend *sh = leann_internal_sharded_shard(hc->sharded, g);
+            const uint64_t lo = leann_internal_sharded_lo(hc->sharded, g);
+            leann_filter *part = nullptr;
+            int rc = (!sh || (lo & 7)) ? (leann_set_error("registered filter: shard %zu does not start at a multiple of 8", g), (int)LEANN_ERR_UNSUPPORTED)
+                                       : leann_backend_filter_create(sh, allow + lo / 8, &part);
+            if (rc) { leann_backend_filter_free(f); return rc; }
+            f->parts.push_back(part);
+            f->n_allowed += part->n_allowed;
+        }
+        (void)hipSetDevice(hc->device);
+        *out = f;
+        return LEANN_OK;
+    }
     if (hc->g.n >= (1ull << 32)) {
         leann_set_error("leann_backend_filter_create: the index has 2^32 rows or more");
         return LEANN_ERR_INVALID;
@@ -495,6 +505,11 @@ extern "C" int leann_backend_filter_create(const leann_backend *hc, const uint8_
 extern "C" size_t leann_backend_filter_count(const leann_filter *f) { return f ? f->n_allowed : 0; }
 extern "C" void leann_backend_filter_free(leann_filter *f) {
     if (!f) return;
+    if (!f->parts.empty()) {
+        for (auto *p : f->parts) leann_backend_filter_free(p);
+        delete f;
+        return;
+    }
     (void)hipSetDevice(f->device);
     (void)hipDeviceSynchronize(); // searches on any stream may still be reading the bitmap / the list
     leann_internal_scratch_release(f->d_list);
@@ -537,7 +552,16 @@ extern "C" int leann_backend_search_filtered_exact_batch_device(const leann_back
         leann_set_error("leann_backend_search_filtered_exact_batch_device: null/zero argument");
         return LEANN_ERR_INVALID;
     }
-    NOT_ON_SHARDED(h, "exact filtered search");
+    if (h->sharded) { // every shard scans its own allowed rows; lists merged by (dist, key)
+        if (allow_stride && allow_stride < (h->g.n + 7) / 8) {
+            leann_set_error("filtered search: allow_stride %zu is smaller than the %zu-byte bitmap", allow_stride, (size_t)(h->g.n + 7) / 8);
+            return LEANN_ERR_INVALID;
+        }
+        if (nq == 0) return LEANN_OK;
+        ShardFilterArgs fa;
+        fa.d_allow = d_allow; fa.allow_stride = allow_stride; fa.exact = true;
+        return leann_internal_sharded_search(h->sharded, d_queries, nq, top_k, 0, fa, d_keys, d_dists, d_counts, nullptr, (hipStream_t)stream, nullptr);
+    }
     if (h->g.feat_h) {
         leann_set_error("exact filtered search needs stored vectors; this index recomputes them from features (use leann_recompute_search_batch_device with an allow mask)");
         return LEANN_ERR_UNSUPPORTED;
@@ -563,7 +587,8 @@ static int search_filtered_batch_host_impl(const leann_backend *hc, const float 
     // exact scan of the allowed rows, or the walk with the filter inside?  FILTER_AUTO (registered filters only: the count is known):
     // exact up to 5 % of the rows / 64k rows for small batches, 1.5 % for large ones, when the index stores vectors
     bool exact = mode == FILTER_EXACT;
-    if (mode == FILTER_AUTO && flt && hc && !hc->g.feat_h && top_k <= 1024) {
+    const bool stored_vectors = hc && !(hc->sharded ? leann_internal_sharded_shard(hc->sharded, 0)->g.feat_h : hc->g.feat_h);
+    if (mode == FILTER_AUTO && flt && hc && stored_vectors && top_k <= 1024) {
         const double frac = nq <= 64 ? 0.05 : 0.015;
         exact = flt->n_allowed <= std::max<size_t>((size_t)(frac * (double)hc->g.n), nq <= 64 ? 65536 : 0);
     }
@@ -596,10 +621,6 @@ static int search_filtered_batch_host_impl(const leann_backend *hc, const float 
     }
     const size_t d = h->g.d, qf = nq * d, no = nq * top_k;
     const size_t ns = 1; // (a composite handle reduces its per-shard counters to [nq x 4] itself, shard.hip)
-    if (h->sharded && (exact || flt)) {
-        leann_set_error("exact / registered-filter search is not available on a sharded handle (the in-traversal filter is)");
-        return fail(LEANN_ERR_UNSUPPORTED);
-    }
     auto grow = [&](void **p, size_t &cap, size_t need, size_t elt) -> int {
         if (need <= cap) return 0;
         (void)hipFree(*p);
@@ -663,7 +684,17 @@ static int search_filtered_batch_host_impl(const leann_backend *hc, const float 
     a.out_stats = zero_copy ? reinterpret_cast<uint32_t *>(w->pin + o_stats) : w->d_stats;
     a.allow = flt ? flt->d_allow : (allow ? w->d_allow : nullptr);
     a.allow_stride = flt ? 0 : allow_stride;
-    if (exact && flt) {
+    if (h->sharded) { // composite handle: the same decision (exact / walk) for every shard, per-shard lists merged by (dist, key)
+        ShardFilterArgs fa;
+        fa.exact = exact;
+        if (flt) fa.sub = flt->parts.data();
+        else { fa.d_allow = a.allow; fa.allow_stride = a.allow_stride; }
+        if (flt && flt->parts.size() != leann_internal_sharded_count(h->sharded)) {
+            leann_set_error("registered filter was not made for this sharded handle");
+            return fail(LEANN_ERR_INVALID);
+        }
+        rc = leann_internal_sharded_search(h->sharded, w->d_q, nq, top_k, complexity, fa, w->d_keys, w->d_dists, w->d_counts, w->d_stats, st, nullptr);
+    } else if (exact && flt) {
         if (h->g.feat_h) {
             leann_set_error("exact filtered search needs stored vectors; this index recomputes them from features");
             return fail(LEANN_ERR_UNSUPPORTED);
@@ -679,9 +710,6 @@ static int search_filtered_batch_host_impl(const leann_backend *hc, const float 
         if (hipMemsetAsync(w->d_stats, 0, nq * 16, st) != hipSuccess) return fail(LEANN_ERR_DEVICE);
         rc = leann_internal_filtered_exact(h->g.X, h->g.n, h->g.d, h->g.ld, w->d_q, nq, top_k, w->d_allow, allow_stride, h->key_offset,
                                            w->d_keys, w->d_dists, w->d_counts, st);
-    } else if (h->sharded) {
-        rc = leann_internal_sharded_search(h->sharded, w->d_q, nq, top_k, complexity, a.allow, a.allow_stride, w->d_keys, w->d_dists, w->d_counts,
-                                           w->d_stats, st, nullptr);
     } else {
         rc = leann_internal_launch_search(h, a, st);
     }
@@ -1046,6 +1074,20 @@ extern "C" int leann_backend_from_arrays(int backend, const float *vectors, size
         leann_set_error("leann_backend_from_arrays: %s", e.what());
         return LEANN_ERR_IO;
     }
+}
+
+// A composite (sharded) handle holds G graphs, so graph_info / graph_export / feature_rows_export apply per shard: the sub-index of a
+// shard is an ordinary handle (borrowed: it lives as long as the composite one; keys it returns are global positions).
+extern "C" size_t leann_backend_shard_count(const leann_backend *h) { return h && h->sharded ? leann_internal_sharded_count(h->sharded) : 0; }
+extern "C" int leann_backend_shard(const leann_backend *h, size_t g, leann_backend **out) {
+    if (!h || !out) { leann_set_error("leann_backend_shard: null argument"); return LEANN_ERR_INVALID; }
+    *out = nullptr;
+    if (!h->sharded || g >= leann_internal_sharded_count(h->sharded) || !leann_internal_sharded_shard(h->sharded, g)) {
+        leann_set_error("leann_backend_shard: %s", h->sharded ? "no such shard" : "not a sharded handle");
+        return LEANN_ERR_INVALID;
+    }
+    *out = leann_internal_sharded_shard(h->sharded, g);
+    return LEANN_OK;
 }
 
 extern "C" int leann_backend_graph_info(const leann_backend *h, uint64_t *info) {

@@ -120,7 +120,10 @@ int leann_internal_save_to(const leann_backend *h, const std::string &path) {
 
 extern "C" int leann_backend_save(const leann_backend *h, const char *index_path_stem) {
     if (!h || !index_path_stem) { leann_set_error("leann_backend_save: null argument"); return LEANN_ERR_INVALID; }
-    if (h->sharded) { leann_set_error("leann_backend_save is not available on a sharded handle (each shard caches its own graph)"); return LEANN_ERR_UNSUPPORTED; }
+    if (h->sharded) { // every shard as its own self-contained file "<stem>.shard<g>of<G>.index"; leann_backend_open with G devices finds them
+        try { return leann_internal_sharded_save(h->sharded, index_path_stem); }
+        catch (const std::exception &e) { leann_set_error("leann_backend_save: %s", e.what()); return LEANN_ERR_IO; }
+    }
     try {
         HIP_CHECK_RET(hipSetDevice(h->device));
         return leann_internal_save_to(h, leann_internal_index_file(index_path_stem, h->kind));

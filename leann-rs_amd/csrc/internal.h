@@ -88,9 +88,30 @@ bool leann_internal_spec_is_sharded(const char *spec);
 int leann_internal_open_sharded_backend(const char *stem, int backend, size_t dims, const char *spec, leann_backend **out);
 size_t leann_internal_sharded_count(const leann_sharded *s);
 leann_backend *leann_internal_sharded_shard(const leann_sharded *s, size_t g);
-int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size_t nq, size_t top_k, size_t complexity, const uint8_t *d_allow,
-                                  size_t allow_stride, uint64_t *d_keys, float *d_dists, uint32_t *d_counts, uint32_t *d_stats, hipStream_t st,
-                                  uint64_t *ticket);
+// A filter registered on the device (leann_backend_filter_create): the bitmap, the ascending list of allowed positions and its length.
+// On a composite handle: one sub-filter per shard (its slice of the bitmap, on the shard's device); n / n_allowed are the totals.
+struct leann_filter {
+    int device = 0;
+    size_t n = 0, n_allowed = 0;
+    uint8_t *d_allow = nullptr;
+    uint32_t *d_list = nullptr; // scratch-pool block (scan.hip), held for the filter's lifetime
+    std::vector<leann_filter *> parts;
+};
+// how a sharded search filters: a bitmap over GLOBAL positions on the first device (sliced per shard at byte boundaries), or one
+// registered sub-filter per shard; `exact`: scan the allowed rows of every shard instead of walking its graph
+struct ShardFilterArgs {
+    const uint8_t *d_allow = nullptr;
+    size_t allow_stride = 0;
+    const leann_filter *const *sub = nullptr;
+    bool exact = false;
+};
+int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size_t nq, size_t top_k, size_t complexity, const ShardFilterArgs &fa,
+                                  uint64_t *d_keys, float *d_dists, uint32_t *d_counts, uint32_t *d_stats, hipStream_t st, uint64_t *ticket);
+int leann_internal_sharded_save(const leann_sharded *s, const char *index_path_stem);
+uint64_t leann_internal_sharded_lo(const leann_sharded *s, size_t g);
+int leann_internal_filtered_exact_list(const float *d_rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t top_k,
+                                       const uint32_t *d_list, size_t m, uint64_t key_offset, uint64_t *d_keys, float *d_dists,
+                                       uint32_t *d_counts, hipStream_t st);
 extern "C" void leann_sharded_close(leann_sharded *s);
 
 int leann_internal_launch_search(leann_backend *h, SearchArgs a, hipStream_t st);

@@ -21,6 +21,8 @@
 #include "common.cuh"
 #include "../../include/leann_backend.h"
 #include "internal.h"
+#include <thread>
+#include <string>
 #include "recompute_fstat.cuh" // fused_fstat_kernel, tile_features_kernel; bf16x8 / f32x16
 #include <algorithm>
 #include <mutex>
@@ -429,6 +431,19 @@ struct leann_recompute {
     uint16_t *ownF = nullptr;       // leann_recompute_create_host: the handle's own copy of the features
     unsigned char *sEmit = nullptr; // [64 f32 thr | 64 u32 cnt | u32 overflow | pad | 64 x EMIT_CAP u64 list]
     size_t capEmit = 0;
+    // sharded form (leann_recompute_create_sharded): the passages live in `parts` (consecutive position ranges, possibly on different
+    // devices); this handle owns only the gather block and the per-part staging
+    struct Part {
+        const leann_recompute *r = nullptr;
+        hipStream_t st = nullptr;
+        hipEvent_t done = nullptr;
+        unsigned char *stage = nullptr; // remote parts: [queries | keys | scores | counts | mask slice] on the part's device
+        size_t cap_stage = 0;
+    };
+    std::vector<Part> parts;
+    unsigned char *gather = nullptr; // [n_parts x {keys | scores | counts}] on `device`
+    size_t cap_gather = 0;
+    hipEvent_t ev_q = nullptr;
 };
 static int grow_scratch(void **p, size_t *cap, size_t bytes) {
     if (bytes <= *cap) return LEANN_OK;
@@ -631,8 +646,121 @@ extern "C" int leann_recompute_search_batch(const leann_recompute *r, const floa
     (void)hipFree(buf);
     return rc;
 }
+int leann_internal_merge_strided(const void *keys, const void *dists, const void *counts, size_t kstride, size_t dstride, size_t cstride,
+                                 size_t n_shards, size_t nq, size_t k_in, size_t k_out, int descending, uint64_t *d_out_keys,
+                                 float *d_out_dists, uint32_t *d_out_counts, hipStream_t st);
+
+// ---- sharded recompute search -------------------------------------------------------------------
+// RecomputeSearcher::search scores EVERY passage (recompute.rs:86-103); the top-k of a union is the top-k of the per-part top-ks, so the
+// passages split into consecutive position ranges, every part runs its own fused scan (concurrently: one host thread per part, the
+// parts may sit on different devices) and the per-part lists are merged by (score descending, key ascending) — the order of the
+// reference's stable sort (recompute.rs:106).  Per-passage arithmetic does not depend on a passage's neighbours in a tile, so the
+// answer equals the unsharded handle's bit for bit (tests/test_gpu_shard.py).
+extern "C" int leann_recompute_create_sharded(const leann_recompute *const *parts, size_t n_parts, leann_recompute **out) {
+    if (!parts || !out || n_parts == 0 || n_parts > 64) { leann_set_error("leann_recompute_create_sharded: invalid arguments"); return LEANN_ERR_INVALID; }
+    *out = nullptr;
+    for (size_t g = 0; g < n_parts; g++) {
+        const leann_recompute *p = parts[g];
+        if (!p || !p->parts.empty() || p->d != parts[0]->d || p->h != parts[0]->h || p->L != parts[0]->L ||
+            (g && p->key_offset != parts[g - 1]->key_offset + parts[g - 1]->n) || (g && ((p->key_offset - parts[0]->key_offset) & 7))) {
+            leann_set_error("leann_recompute_create_sharded: part %zu is null, itself sharded, of another shape, or does not continue part %zu's "
+                            "position range at a multiple of 8", g, g ? g - 1 : 0);
+            return LEANN_ERR_INVALID;
+        }
+    }
+    leann_recompute *r = new leann_recompute();
+    r->device = parts[0]->device;
+    r->d = parts[0]->d; r->h = parts[0]->h; r->hp = parts[0]->hp; r->dp = parts[0]->dp; r->ld = parts[0]->ld; r->L = parts[0]->L;
+    r->key_offset = parts[0]->key_offset;
+    bool ok = hipSetDevice(r->device) == hipSuccess && hipEventCreateWithFlags(&r->ev_q, hipEventDisableTiming) == hipSuccess;
+    for (size_t g = 0; ok && g < n_parts; g++) {
+        leann_recompute::Part pt;
+        pt.r = parts[g];
+        r->n += parts[g]->n;
+        ok = hipSetDevice(parts[g]->device) == hipSuccess && hipStreamCreateWithFlags(&pt.st, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&pt.done, hipEventDisableTiming) == hipSuccess;
+        r->parts.push_back(pt);
+    }
+    (void)hipSetDevice(r->device);
+    if (!ok) {
+        leann_set_error("leann_recompute_create_sharded: stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
+        leann_recompute_close(r);
+        return LEANN_ERR_DEVICE;
+    }
+    *out = r;
+    return LEANN_OK;
+}
+
+static int sharded_recompute_search(leann_recompute *r, const float *d_queries, size_t nq, size_t top_k, const uint8_t *d_allow_mask,
+                                    uint64_t *d_keys, float *d_scores, uint32_t *d_counts, hipStream_t st) {
+    const size_t G = r->parts.size();
+    if (G * top_k > 12288) { leann_set_error("sharded recompute search: parts x top_k = %zu x %zu exceeds the merge kernel's 12288 entries", G, top_k); return LEANN_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(r->mu); // one search at a time per handle, like a plain handle's scratch
+    HIP_CHECK_RET(hipSetDevice(r->device));
+    const size_t okeys = 0, oscores = nq * top_k * 8, ocounts = nq * top_k * 12, blk = (nq * top_k * 12 + nq * 4 + 15) & ~(size_t)15;
+    if (int rc = grow_scratch((void **)&r->gather, &r->cap_gather, G * blk)) return rc;
+    HIP_CHECK_RET(hipEventRecord(r->ev_q, st)); // queries (and the mask) are ready
+    std::vector<int> rcs(G, LEANN_OK);
+    std::vector<std::string> errs(G);
+    auto run_part = [&](size_t g) {
+        leann_recompute::Part &pt = r->parts[g];
+        const leann_recompute *p = pt.r;
+        auto fail = [&](const char *what) { leann_set_error("sharded recompute search, part %zu: %s failed: %s", g, what, hipGetErrorString(hipGetLastError())); return (int)LEANN_ERR_DEVICE; };
+        if (hipSetDevice(p->device) != hipSuccess) return fail("hipSetDevice");
+        if (hipStreamWaitEvent(pt.st, r->ev_q, 0) != hipSuccess) return fail("hipStreamWaitEvent");
+        const bool remote = p->device != r->device;
+        const size_t mask_off = (size_t)((p->key_offset - r->key_offset) / 8), mask_b = d_allow_mask ? (p->n + 7) / 8 : 0;
+        const float *q = d_queries;
+        const uint8_t *mask = d_allow_mask ? d_allow_mask + mask_off : nullptr;
+        unsigned char *outb = r->gather + g * blk;
+        if (remote) { // queries (and the part's slice of the mask) travel to the part's device, its lists travel back
+            const size_t oq = 0, ob = (nq * r->d * 4 + 15) & ~(size_t)15, om = ob + blk, need = om + mask_b + 16;
+            if (need > pt.cap_stage) {
+                (void)hipFree(pt.stage); pt.stage = nullptr; pt.cap_stage = 0;
+                if (hipMalloc((void **)&pt.stage, need) != hipSuccess) return fail("hipMalloc");
+                pt.cap_stage = need;
+            }
+            if (hipMemcpyPeerAsync(pt.stage + oq, p->device, d_queries, r->device, nq * r->d * 4, pt.st) != hipSuccess) return fail("peer copy of the queries");
+            if (mask_b && hipMemcpyPeerAsync(pt.stage + om, p->device, d_allow_mask + mask_off, r->device, mask_b, pt.st) != hipSuccess) return fail("peer copy of the mask");
+            q = (const float *)(pt.stage + oq);
+            mask = mask_b ? pt.stage + om : nullptr;
+            outb = pt.stage + ob;
+        }
+        int rc = leann_recompute_search_batch_device(p, q, nq, top_k, mask, (uint64_t *)(outb + okeys), (float *)(outb + oscores),
+                                                     (uint32_t *)(outb + ocounts), pt.st);
+        if (rc) return rc;
+        if (remote && hipMemcpyPeerAsync(r->gather + g * blk, r->device, outb, p->device, blk, pt.st) != hipSuccess) return fail("peer copy of the results");
+        if (hipEventRecord(pt.done, pt.st) != hipSuccess) return fail("hipEventRecord");
+        return (int)LEANN_OK;
+    };
+    std::vector<std::thread> th;
+    for (size_t g = 1; g < G; g++)
+        th.emplace_back([&, g] { rcs[g] = run_part(g); if (rcs[g]) errs[g] = leann_last_error(); });
+    rcs[0] = run_part(0);
+    if (rcs[0]) errs[0] = leann_last_error();
+    for (auto &t : th) t.join();
+    (void)hipSetDevice(r->device);
+    for (size_t g = 0; g < G; g++)
+        if (rcs[g]) { leann_set_error("%s", errs[g].c_str()); return rcs[g]; }
+    for (size_t g = 0; g < G; g++) HIP_CHECK_RET(hipStreamWaitEvent(st, r->parts[g].done, 0));
+    r->last_ms[0] = r->last_ms[1] = r->last_ms[2] = 0.f;
+    for (size_t g = 0; g < G; g++)
+        for (int i = 0; i < 3; i++) r->last_ms[i] = std::max(r->last_ms[i], r->parts[g].r->last_ms[i]);
+    return leann_internal_merge_strided(r->gather + okeys, r->gather + oscores, r->gather + ocounts, blk, blk, blk, G, nq, top_k, top_k, 1, d_keys,
+                                        d_scores, d_counts, st);
+}
+
 extern "C" void leann_recompute_close(leann_recompute *r) {
     if (!r) return;
+    for (auto &pt : r->parts) { // (the parts themselves are borrowed)
+        (void)hipSetDevice(pt.r ? pt.r->device : r->device);
+        if (pt.st) { (void)hipStreamSynchronize(pt.st); (void)hipStreamDestroy(pt.st); }
+        if (pt.done) (void)hipEventDestroy(pt.done);
+        (void)hipFree(pt.stage);
+    }
+    if (!r->parts.empty()) (void)hipSetDevice(r->device);
+    if (r->ev_q) (void)hipEventDestroy(r->ev_q);
+    (void)hipFree(r->gather);
     (void)hipFree(r->Wp);
     (void)hipFree(r->Wraw);
     (void)hipFree(r->sS);
@@ -655,6 +783,7 @@ extern "C" int leann_recompute_last_timing(const leann_recompute *r, float *ms3)
 // materialise the embeddings of rows [row0, row0 + rows) into d_out [rows x ld] (tests / validation)
 extern "C" int leann_recompute_encode_device(const leann_recompute *r, uint64_t row0, uint64_t rows, float *d_out, void *stream) {
     if (!r || !d_out || row0 + rows > r->n) { leann_set_error("leann_recompute_encode_device: invalid arguments"); return LEANN_ERR_INVALID; }
+    if (!r->parts.empty()) { leann_set_error("leann_recompute_encode_device: a sharded handle holds no features of its own (encode through its parts)"); return LEANN_ERR_UNSUPPORTED; }
     if (rows == 0) return LEANN_OK;
     HIP_CHECK_RET(hipSetDevice(r->device));
     return launch_encode(r, row0, rows, d_out, (hipStream_t)stream);
@@ -685,6 +814,8 @@ extern "C" int leann_recompute_search_batch_device(const leann_recompute *r, con
         return LEANN_ERR_INVALID;
     }
     if (nq == 0) return LEANN_OK;
+    if (!r->parts.empty())
+        return sharded_recompute_search(const_cast<leann_recompute *>(r), d_queries, nq, top_k, d_allow_mask, d_keys, d_scores, d_counts, (hipStream_t)stream);
     HIP_CHECK_RET(hipSetDevice(r->device));
     // The early filter of recompute.rs:62-79: the reference fetches, and therefore embeds, only the passages that pass the filter.
     // A selective mask is compacted into the list of allowed positions and only those rows go through the fused kernel (same
@@ -873,6 +1004,7 @@ __global__ void bf16_to_f32_kernel(const uint16_t *__restrict__ in, size_t n, fl
 extern "C" int leann_recompute_build_index(const leann_recompute *r, int backend, size_t graph_degree, size_t complexity,
                                            leann_backend **out) {
     if (!r || !out) { leann_set_error("leann_recompute_build_index: null argument"); return LEANN_ERR_INVALID; }
+    if (!r->parts.empty()) { leann_set_error("leann_recompute_build_index: build one index per part and join them with leann_sharded_from_handles"); return LEANN_ERR_UNSUPPORTED; }
     if (r->L != 1 || r->mask) {
         leann_set_error("recompute-on graph search needs one feature vector per passage (no token pooling): the feature-space "
                         "distance <f, W q> / ||W^T f|| is only exact for bf16-exact features");

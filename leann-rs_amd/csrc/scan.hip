@@ -738,7 +738,7 @@ int leann_internal_filtered_exact(const float *d_rows, size_t n, size_t dims, si
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cross-shard merge.  One wave per query; n_shards*k_in <= 4096 entries.
+// Cross-shard merge.  One wave per query; n_shards*k_in <= 12288 entries (144 KiB of LDS).
 // Order: ascending (orderable(dist), key)  [descending != 0: descending score, ascending key].
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) merge_topk_kernel(const unsigned char *__restrict__ keys, const unsigned char *__restrict__ dists,
@@ -795,13 +795,15 @@ int leann_internal_merge_strided(const void *keys, const void *dists, const void
                                  size_t n_shards, size_t nq, size_t k_in, size_t k_out, int descending, uint64_t *d_out_keys,
                                  float *d_out_dists, uint32_t *d_out_counts, hipStream_t st) {
     if (!keys || !dists || !counts || !d_out_keys || !d_out_dists || !d_out_counts || n_shards == 0 ||
-        k_in == 0 || k_out == 0 || n_shards * k_in > 4096) {
+        k_in == 0 || k_out == 0 || n_shards * k_in > 12288) {
         leann_set_error("leann_merge_topk_device: invalid arguments (shards=%zu k_in=%zu k_out=%zu)", n_shards, k_in, k_out);
         return LEANN_ERR_INVALID;
     }
     if (nq == 0) return LEANN_OK;
     size_t total = n_shards * k_in;
     size_t lds = ((total * 4 + 7) & ~(size_t)7) + total * 8;
+    if (lds > 64 * 1024) // > 4096 entries (e.g. 8 shards x fetch_k = 5 x 200 of a filtered / hybrid query, searcher.rs:129-133): up to 144 KiB of the 160
+        HIP_CHECK_RET(hipFuncSetAttribute((const void *)merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), lds, st, (const unsigned char *)keys, (const unsigned char *)dists,
                        (const unsigned char *)counts, kstride, dstride, cstride, (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k_in,
                        (uint32_t)k_out, descending, d_out_keys, d_out_dists, d_out_counts);

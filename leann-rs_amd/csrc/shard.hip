@@ -271,31 +271,70 @@ extern "C" int leann_sharded_build_device(int backend, const float *const *d_vec
 
 // Rows of a sharded open come from "<stem>.embeddings" (the reference builder's file, src/index/embeddings.rs) or, failing that, from
 // the rows inside this library's own version-1 index file.  Each shard's graph is cached as "<stem>.shard<g>of<G>.gpu.index".
+// "<stem>.shard<g>of<G>.index": a shard saved by leann_backend_save (self-contained); "....gpu.index": a graph cache derived from the row source
+static std::string shard_file(const char *stem, size_t g, size_t G, int backend, bool cache) {
+    char tag[80];
+    snprintf(tag, sizeof tag, "shard%zuof%zu.%s%s", g, G, cache ? "gpu." : "", backend == LEANN_BACKEND_DISKANN ? "diskann" : "index");
+    return leann_internal_with_extension(stem, tag);
+}
+// This library's own version-1 index file comes FIRST: `leann update` appends to the index (leann_backend_add rewrites the file with
+// n_old + n rows) but never to "<stem>.embeddings" — only the builder writes that (src/index/builder.rs:105-113, src/cli/update.rs:169-223)
+// — so after an update the embeddings file is the stale one, and a sharded open that preferred it served an index without the new
+// passages.  The embeddings file is the source for foreign (stock usearch / diskann-rs) index files only.
 static int rows_source(const char *stem, int backend, size_t dims, std::string *path, uint64_t *offset, size_t *n) {
     const std::string emb = leann_internal_with_extension(stem, "embeddings");
-    struct stat st{};
-    if (stat(emb.c_str(), &st) == 0 && dims && st.st_size > 0 && (uint64_t)st.st_size % (dims * 4) == 0) {
-        *path = emb; *offset = 0; *n = (size_t)st.st_size / (dims * 4);
-        return LEANN_OK;
-    }
     const std::string own = leann_internal_index_file(stem, backend);
+    struct stat st{};
+    size_t emb_rows = 0;
+    const bool have_emb = stat(emb.c_str(), &st) == 0 && dims && st.st_size > 0 && (uint64_t)st.st_size % (dims * 4) == 0;
+    if (have_emb) emb_rows = (size_t)st.st_size / (dims * 4);
     FILE *f = fopen(own.c_str(), "rb");
-    if (!f) {
-        leann_set_error("sharded open: neither %s nor %s exists", emb.c_str(), own.c_str());
-        return LEANN_ERR_NOT_FOUND;
+    if (f) {
+        unsigned char hd[128];
+        const bool ok = fread(hd, 1, 128, f) == 128 && !memcmp(hd, "LEANNGX1", 8);
+        fclose(f);
+        uint32_t version = 0, d = 0, M = 0, M0 = 0;
+        uint64_t nn = 0, nul = 0;
+        if (ok) { memcpy(&version, hd + 8, 4); memcpy(&nn, hd + 16, 8); memcpy(&d, hd + 24, 4); memcpy(&M, hd + 28, 4); memcpy(&M0, hd + 32, 4); memcpy(&nul, hd + 56, 8); }
+        if (ok && version == 1 && (!dims || d == dims) && stat(own.c_str(), &st) == 0 &&
+            (uint64_t)st.st_size == 128 + nn + 4 * nn + 4 * nn * M0 + 4 * nul * M + 4 * nn * d) {
+            if (have_emb && emb_rows != nn)
+                leann_log(LEANN_LOG_WARN, "%s holds %zu rows, %s holds %llu: partitioning the index file's rows (the embeddings file is not updated by `leann update`)",
+                          emb.c_str(), emb_rows, own.c_str(), (unsigned long long)nn);
+            *path = own; *offset = 128 + nn + 4 * nn + 4 * nn * M0 + 4 * nul * M; *n = (size_t)nn;
+            return LEANN_OK;
+        }
+        if (!have_emb) {
+            leann_set_error("sharded open: %s holds no rows to partition (foreign, recompute-on or corrupt file) and %s is missing", own.c_str(), emb.c_str());
+            return LEANN_ERR_FORMAT;
+        }
     }
-    unsigned char hd[128];
-    const bool ok = fread(hd, 1, 128, f) == 128 && !memcmp(hd, "LEANNGX1", 8);
-    fclose(f);
-    uint32_t version = 0, d = 0, M = 0, M0 = 0;
-    uint64_t nn = 0, nul = 0;
-    if (ok) { memcpy(&version, hd + 8, 4); memcpy(&nn, hd + 16, 8); memcpy(&d, hd + 24, 4); memcpy(&M, hd + 28, 4); memcpy(&M0, hd + 32, 4); memcpy(&nul, hd + 56, 8); }
-    if (!ok || version != 1 || (dims && d != dims) || stat(own.c_str(), &st) != 0 ||
-        (uint64_t)st.st_size != 128 + nn + 4 * nn + 4 * nn * M0 + 4 * nul * M + 4 * nn * d) {
-        leann_set_error("sharded open: %s holds no rows to partition (foreign, recompute-on or corrupt file) and %s is missing", own.c_str(), emb.c_str());
-        return LEANN_ERR_FORMAT;
+    if (have_emb) { *path = emb; *offset = 0; *n = emb_rows; return LEANN_OK; }
+    leann_set_error("sharded open: neither %s nor %s exists", emb.c_str(), own.c_str());
+    return LEANN_ERR_NOT_FOUND;
+}
+
+// shards written by leann_backend_save on a composite handle: all G files present and loadable -> the index, no rebuild
+static int saved_shards(const char *stem, int backend, size_t dims, const std::vector<int> &devs, std::vector<leann_backend *> *hs) {
+    const size_t G = devs.size();
+    struct stat st{};
+    for (size_t g = 0; g < G; g++)
+        if (stat(shard_file(stem, g, G, backend, false).c_str(), &st) != 0) return LEANN_ERR_NOT_FOUND;
+    uint64_t lo = 0;
+    for (size_t g = 0; g < G; g++) {
+        std::string why;
+        leann_backend *h = nullptr;
+        int rc = leann_internal_load_own_file(shard_file(stem, g, G, backend, false), backend, dims, devs[g], &h, &why);
+        if (rc) {
+            for (auto *p : *hs) if (p) leann_backend_close(p);
+            hs->assign(G, nullptr);
+            leann_log(LEANN_LOG_WARN, "ignoring saved shard files of %s: shard %zu: %s", stem, g, why.empty() ? leann_last_error() : why.c_str());
+            return rc;
+        }
+        h->key_offset = lo;
+        lo += h->g.n;
+        (*hs)[g] = h;
     }
-    *path = own; *offset = 128 + nn + 4 * nn + 4 * nn * M0 + 4 * nul * M; *n = (size_t)nn;
     return LEANN_OK;
 }
 
@@ -345,6 +384,14 @@ extern "C" int leann_sharded_open(const char *index_path_stem, int backend, size
     std::vector<int> devs;
     if (int rc = parse_device_list(device_spec, &devs)) return rc;
     try {
+        {
+            std::vector<leann_backend *> saved(devs.size(), nullptr);
+            if (saved_shards(index_path_stem, backend, dims, devs, &saved) == LEANN_OK) {
+                int rc = leann_sharded_from_handles(saved.data(), saved.size(), 1, out);
+                if (rc) for (auto *h : saved) leann_backend_close(h);
+                return rc;
+            }
+        }
         std::string src;
         uint64_t off = 0;
         size_t n = 0;
@@ -359,10 +406,8 @@ extern "C" int leann_sharded_open(const char *index_path_stem, int backend, size
         for (size_t g = 0; g < G; g++)
             th.emplace_back([&, g] {
                 const uint64_t lo = shard_lo(n, G, g), hi = shard_lo(n, G, g + 1);
-                char tag[64];
-                snprintf(tag, sizeof tag, "shard%zuof%zu.gpu.%s", g, G, backend == LEANN_BACKEND_DISKANN ? "diskann" : "index");
                 try {
-                    rcs[g] = open_one_shard(src, off, leann_internal_with_extension(index_path_stem, tag), st.st_mtime, backend, dims, lo,
+                    rcs[g] = open_one_shard(src, off, shard_file(index_path_stem, g, G, backend, true), st.st_mtime, backend, dims, lo,
                                             (size_t)(hi - lo), devs[g], &hs[g]);
                 } catch (const std::exception &e) {
                     leann_set_error("%s", e.what());
@@ -471,11 +516,14 @@ extern "C" int leann_sharded_attach(leann_backend *local, const void *unique_id1
 // The traversal is queued behind `stream`; exchange and merge run on the handle's own stream.  ticket == nullptr: `stream` also waits
 // for the merge (results are ordered on `stream`).
 int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size_t nq, size_t top_k, size_t complexity,
-                                  const uint8_t *d_allow, size_t allow_stride, uint64_t *d_keys, float *d_dists, uint32_t *d_counts,
+                                  const ShardFilterArgs &fa, uint64_t *d_keys, float *d_dists, uint32_t *d_counts,
                                   uint32_t *d_stats, hipStream_t st, uint64_t *ticket) {
     if (!s || !d_queries || !d_keys || !d_dists || !d_counts || top_k == 0) { leann_set_error("sharded search: null/zero argument"); return LEANN_ERR_INVALID; }
+    const uint8_t *d_allow = fa.d_allow;
+    const size_t allow_stride = fa.allow_stride;
     const size_t G = s->rccl ? (size_t)s->world : s->shards.size();
-    if (G * top_k > 4096) { leann_set_error("sharded search: shards x top_k = %zu x %zu exceeds the merge kernel's 4096 entries", G, top_k); return LEANN_ERR_INVALID; }
+    if (G * top_k > 12288) { leann_set_error("sharded search: shards x top_k = %zu x %zu exceeds the merge kernel's 12288 entries", G, top_k); return LEANN_ERR_INVALID; }
+    if (s->rccl && (fa.sub || fa.exact)) { leann_set_error("sharded search over RCCL: registered / exact filters are a one-process feature"); return LEANN_ERR_UNSUPPORTED; }
     if (d_allow && s->rccl && (s->shards[0].lo & 7)) { leann_set_error("sharded filtered search: the shard does not start at a multiple of 8"); return LEANN_ERR_UNSUPPORTED; }
     if (nq == 0) return LEANN_OK;
     std::lock_guard<std::mutex> lk(s->mu); // enqueue phase only; the work itself is asynchronous
@@ -531,9 +579,21 @@ int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size
                 if (int rc = grow_dev((void **)&sd.d_stats, &sd.cap_stats, nq * 16)) return rc;
                 stats_g = sd.d_stats;
             }
-            int rc = leann_backend_search_filtered_batch_device(sd.h, q, nq, top_k, complexity, allow_g, allow_stride,
-                                                                (uint64_t *)(blkp + koff), (float *)(blkp + doff), (uint32_t *)(blkp + coff),
-                                                                stats_g, sd.st);
+            uint64_t *ok = (uint64_t *)(blkp + koff);
+            float *od = (float *)(blkp + doff);
+            uint32_t *oc = (uint32_t *)(blkp + coff);
+            int rc;
+            if (fa.exact && stats_g) HIP_CHECK_RET(hipMemsetAsync(stats_g, 0, nq * 16, sd.st)); // no walk: no evaluations / hops to count
+            if (fa.sub && fa.exact) // registered filter, answered exactly: the shard's compacted list of allowed rows is scanned
+                rc = sd.h->g.feat_h ? (leann_set_error("exact filtered search needs stored vectors; this index recomputes them from features"), (int)LEANN_ERR_UNSUPPORTED)
+                                    : leann_internal_filtered_exact_list(sd.h->g.X, sd.h->g.d, sd.h->g.ld, q, nq, top_k, fa.sub[g]->d_list, fa.sub[g]->n_allowed,
+                                                                         sd.h->key_offset, ok, od, oc, sd.st);
+            else if (fa.sub) // registered filter inside the walk: the sub-filter's bitmap lives on the shard's device already
+                rc = leann_backend_search_filtered_batch_device(sd.h, q, nq, top_k, complexity, fa.sub[g]->d_allow, 0, ok, od, oc, stats_g, sd.st);
+            else if (fa.exact)
+                rc = leann_backend_search_filtered_exact_batch_device(sd.h, q, nq, top_k, allow_g, allow_stride, ok, od, oc, sd.st);
+            else
+                rc = leann_backend_search_filtered_batch_device(sd.h, q, nq, top_k, complexity, allow_g, allow_stride, ok, od, oc, stats_g, sd.st);
             if (rc) { (void)hipSetDevice(s->primary); return rc; }
             if (remote) HIP_CHECK_RET(hipMemcpyPeerAsync(sl.gather + g * blk, s->primary, sd.d_out, sd.device, blk, sd.st));
             if (remote && d_stats) HIP_CHECK_RET(hipMemcpyPeerAsync(sl.stats + g * nq * 4, s->primary, sd.d_stats, sd.device, nq * 16, sd.st));
@@ -559,14 +619,29 @@ int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size
 
 extern "C" int leann_sharded_search_batch_device(const leann_sharded *s, const float *d_queries, size_t nq, size_t top_k, size_t complexity,
                                                  uint64_t *d_keys, float *d_dists, uint32_t *d_counts, uint32_t *d_stats, void *stream) {
-    return leann_internal_sharded_search(const_cast<leann_sharded *>(s), d_queries, nq, top_k, complexity, nullptr, 0, d_keys, d_dists, d_counts,
+    return leann_internal_sharded_search(const_cast<leann_sharded *>(s), d_queries, nq, top_k, complexity, ShardFilterArgs{}, d_keys, d_dists, d_counts,
                                          d_stats, (hipStream_t)stream, nullptr);
+}
+uint64_t leann_internal_sharded_lo(const leann_sharded *s, size_t g) { return s && g < s->shards.size() ? s->shards[g].lo : 0; }
+
+// leann_backend_save on a composite handle: every shard as a self-contained file of this library's own format,
+// "<stem>.shard<g>of<G>.index" / ".diskann"; leann_backend_open(stem, ..., a list of G devices) finds them again (saved_shards below).
+int leann_internal_sharded_save(const leann_sharded *s, const char *index_path_stem) {
+    if (!s || s->rccl) { leann_set_error("leann_backend_save: a one-process-per-GPU (RCCL) group saves each rank's own shard handle"); return LEANN_ERR_UNSUPPORTED; }
+    const size_t G = s->shards.size();
+    for (size_t g = 0; g < G; g++) {
+        const ShardDev &sd = s->shards[g];
+        HIP_CHECK_RET(hipSetDevice(sd.device));
+        if (int rc = leann_internal_save_to(sd.h, shard_file(index_path_stem, g, G, sd.h->kind, false))) { (void)hipSetDevice(s->primary); return rc; }
+    }
+    HIP_CHECK_RET(hipSetDevice(s->primary));
+    return LEANN_OK;
 }
 extern "C" int leann_sharded_search_batch_device_async(const leann_sharded *s, const float *d_queries, size_t nq, size_t top_k,
                                                        size_t complexity, uint64_t *d_keys, float *d_dists, uint32_t *d_counts,
                                                        uint32_t *d_stats, void *stream, uint64_t *ticket) {
     if (!ticket) { leann_set_error("leann_sharded_search_batch_device_async: null ticket"); return LEANN_ERR_INVALID; }
-    return leann_internal_sharded_search(const_cast<leann_sharded *>(s), d_queries, nq, top_k, complexity, nullptr, 0, d_keys, d_dists, d_counts,
+    return leann_internal_sharded_search(const_cast<leann_sharded *>(s), d_queries, nq, top_k, complexity, ShardFilterArgs{}, d_keys, d_dists, d_counts,
                                          d_stats, (hipStream_t)stream, ticket);
 }
 // `stream` waits for the exchange + merge of `ticket`.  At most two tickets may be outstanding (two result slots rotate): wait for

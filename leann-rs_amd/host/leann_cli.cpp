@@ -214,13 +214,14 @@ static int run_search(int argc, char **argv) {
 // leann build --index-dir DIR --passages-jsonl FILE [--backend-name hnsw|diskann] [--graph-degree 32]
 //             [--complexity 64] [--dimensions 128] [--embedding-mode synthetic|synthetic-linear] [--recompute] [--pruned]
 //             [--recompute-graph]
-// --recompute       also write documents.embeddings (src/index/builder.rs:105-113), so that the index can be pruned later
+// --recompute       also write documents.embeddings (only in recompute mode, src/index/builder.rs:105-113), so that the index can be
+//                   pruned later; off by default like the reference (meta.is_recompute = args.recompute)
 // --pruned          no ANN file and no embeddings: the reference's pruned state (brute-force recompute at query time)
 // --recompute-graph (needs --embedding-mode synthetic-linear) graph + compact encoder inputs, no vectors
 static int run_build(int argc, char **argv) {
     std::string dir, jsonl, backend_name = "hnsw", mode = "synthetic";
     size_t degree = 32, complexity = 64, dims = 128;
-    bool pruned = false, recompute = true, rgraph = false;
+    bool pruned = false, recompute = false, rgraph = false; // is_recompute = args.recompute, default false (src/cli/build.rs:363)
     for (int i = 0; i < argc; i++) {
         std::string s = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) throw Error("missing value for " + s); return argv[++i]; };

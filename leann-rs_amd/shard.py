@@ -135,6 +135,9 @@ class ShardedSearcher:
         for queries in batches:
             stream = torch.cuda.current_stream(queries.device).cuda_stream if queries.is_cuda else 0
             lib = self._library(queries)
+            if lib is not None and descending:
+                raise RuntimeError("ShardedSearcher: the library's RCCL path merges ascending (dist, key); descending (recompute scores) "
+                                   "lists go through leann_recompute_create_sharded or the torch exchange")
             if lib is not None:
                 out = self._outputs(queries, top_k)
                 ticket = lib.search_batch_device_async(queries.data_ptr(), queries.shape[0], top_k, complexity, out[0].data_ptr(),
@@ -164,6 +167,9 @@ class ShardedSearcher:
         """queries: [nq, dims] tensor, identical on every rank.  Returns global (keys, dists, counts)."""
         stream = torch.cuda.current_stream(queries.device).cuda_stream if queries.is_cuda else 0
         lib = self._library(queries)
+        if lib is not None and descending:
+            raise RuntimeError("ShardedSearcher: the library's RCCL path merges ascending (dist, key); descending (recompute scores) "
+                               "lists go through leann_recompute_create_sharded or the torch exchange")
         if lib is not None:
             out = self._outputs(queries, top_k)
             lib.search_batch_device(queries.data_ptr(), queries.shape[0], top_k, complexity, out[0].data_ptr(), out[1].data_ptr(),

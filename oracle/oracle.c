@@ -737,8 +737,36 @@ static uint32_t list_len(const uint32_t *l, uint32_t cap) {
  * alpha (alpha = 1: HNSW; Vamana RobustPrune Alg. 2 uses alpha >= 1):
  * walk candidates by ascending (dist to p, id); keep c unless some kept r has
  * alpha * dist(c, r) <= dist(c, p)   [Vamana]   /   dist(c, r) < dist(c, p)   [HNSW, alpha == 0 flag] */
+/* RobustPrune in two forms.  The paper's Alg. 2 walks the pool once with alpha.  DiskANN's implementation (occlude_list) walks it
+ * with alpha = 1.0 first — the diverse core, drawn from the WHOLE pool — and only fills the slots still free with the relaxed alpha.
+ * On data of high intrinsic dimension the one-stage rule at alpha = 1.2 occludes almost nothing, a list becomes the R nearest of the
+ * pool, and at R = 32 the graph stops being navigable as the corpus grows (scripts/exp/vamana_scale.py / vamana_seq_oracle.py:
+ * profiles/r03_vamana_scale.md).  Which form diskann-rs 0.3.4 uses cannot be checked offline; the builders here default to the
+ * two-stage form (orc_set_vamana_two_stage(0) = the paper's). */
+static int g_two_stage = 1;
+void orc_set_vamana_two_stage(int on) { g_two_stage = on; }
+static uint32_t select_two_stage(const orc_graph *g, const uint64_t *cands, uint32_t nc, uint32_t lim, float alpha, uint32_t *out) {
+    uint8_t *taken = (uint8_t *)calloc(nc ? nc : 1, 1);
+    uint32_t ns = 0;
+    for (int stage = 0; stage < 2 && ns < lim; stage++) {
+        const float a = stage == 0 ? 1.0f : alpha;
+        for (uint32_t i = 0; i < nc && ns < lim; i++) {
+            if (taken[i]) continue;
+            uint32_t cid = key_id(cands[i]);
+            float dcp = key_dist(cands[i]);
+            const float *xc = g->X + (size_t)cid * g->ld;
+            int good = 1;
+            for (uint32_t s = 0; s < ns && good; s++)
+                if (a * gdist(g, xc, out[s]) <= dcp) good = 0;
+            if (good) { out[ns++] = cid; taken[i] = 1; }
+        }
+    }
+    free(taken);
+    return ns;
+}
 static uint32_t select_heuristic(const orc_graph *g, const uint64_t *cands, uint32_t nc, uint32_t lim,
                                  float alpha, uint32_t *out) {
+    if (alpha > 1.0f && g_two_stage) return select_two_stage(g, cands, nc, lim, alpha, out);
     uint32_t ns = 0;
     for (uint32_t i = 0; i < nc && ns < lim; i++) {
         uint32_t cid = key_id(cands[i]);

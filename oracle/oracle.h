@@ -53,6 +53,7 @@ float orc_dot_canon_ref(const float *a, const float *b, uint32_t d); /* same, sc
 float orc_dot_seq(const float *a, const float *b, uint32_t d);       /* recompute.rs:137-139 literal */
 float orc_dot_seqfma(const float *a, const float *b, uint32_t d);    /* k-ordered fmaf chain (MFMA f32 order) */
 float orc_dot_fast(const float *a, const float *b, uint32_t d);      /* plain AVX2 dot; CPU-baseline timing only */
+void orc_set_vamana_two_stage(int on);                             /* RobustPrune form of the builders: 1 (default) = DiskANN's occlude_list, 0 = the paper's Alg. 2 */
 void orc_set_fast_dot(int on);                                      /* graph search uses orc_dot_fast (timing only) */
 
 uint32_t orc_f32_orderable(float f);

@@ -39,6 +39,7 @@ def lib():
         L.orc_gen_rows.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                    C.c_uint32, C.c_uint64, C.c_uint64, f32p]
         L.orc_set_fast_dot.argtypes = [C.c_int]
+        L.orc_set_vamana_two_stage.argtypes = [C.c_int]
         for n in ("orc_dot_canon", "orc_dot_canon_ref", "orc_dot_seq", "orc_dot_seqfma", "orc_dot_fast"):
             f = getattr(L, n)
             f.restype = C.c_float
@@ -129,9 +130,15 @@ class Graph:
         return cls(h, X)
 
     @classmethod
-    def build_vamana(cls, X, R=32, L=64, alpha=1.2, seed=SEED_LEVELS):
+    def build_vamana(cls, X, R=32, L=64, alpha=1.2, seed=SEED_LEVELS, two_stage=True):
+        """two_stage: RobustPrune as DiskANN implements it (occlude_list: alpha 1.0 over the whole pool, then the relaxed alpha for the
+        free slots) — what the GPU builder does; False = the paper's one-stage Alg. 2 (the round-2 pins were made with it)."""
         X = np.ascontiguousarray(X, np.float32)
-        h = lib().orc_vamana_build(_p(X, f32p), X.shape[0], X.shape[1], R, L, alpha, seed)
+        lib().orc_set_vamana_two_stage(1 if two_stage else 0)
+        try:
+            h = lib().orc_vamana_build(_p(X, f32p), X.shape[0], X.shape[1], R, L, alpha, seed)
+        finally:
+            lib().orc_set_vamana_two_stage(1)
         return cls(h, X)
 
     @classmethod

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--beams", default="128,256,512")
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--fast-dot", action="store_true", help="plain AVX2 dot instead of the canonical tree (not bit-compatible with the GPU; same graph quality)")
+    ap.add_argument("--paper-prune", action="store_true", help="one-stage RobustPrune of the paper (Alg. 2) instead of DiskANN's two-stage occlude_list")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     n, d, k = a.rows, a.d, 10
@@ -40,8 +41,8 @@ def main():
     # exact top-10 by BLAS (f32 GEMM; near-ties do not move a recall figure)
     best = np.full((a.nq, k), -np.inf, np.float32)
     besti = np.zeros((a.nq, k), np.int64)
-    for r0 in range(0, n, 500_000):
-        S = Q @ X[r0:r0 + 500_000].T
+    for r0 in range(0, n, 100_000):  # 2000 x 100k scores + the index array of argpartition: ~2.5 GB at a time
+        S = Q @ X[r0:r0 + 100_000].T
         idx = np.argpartition(-S, k, axis=1)[:, :k]
         sc = np.take_along_axis(S, idx, 1)
         allsc, allid = np.concatenate([best, sc], 1), np.concatenate([besti, idx + r0], 1)
@@ -51,10 +52,11 @@ def main():
     if a.fast_dot:
         po.lib().orc_set_fast_dot(1)
     t0 = time.time()
-    G = po.Graph.build_vamana(X, R=a.R, L=a.L, alpha=1.2)
+    G = po.Graph.build_vamana(X, R=a.R, L=a.L, alpha=1.2, two_stage=not a.paper_prune)
     build_s = time.time() - t0
     print(f"sequential build of {n} x {d}, R={a.R}, L={a.L}: {build_s:.0f}s", flush=True)
-    rec = {"builder": "oracle/oracle.c:orc_vamana_build (sequential, random start graph, 2 passes: alpha 1.0 then 1.2)", "n": n, "d": d, "R": a.R,
+    rec = {"builder": "oracle/oracle.c:orc_vamana_build (sequential, random start graph, 2 passes: alpha 1.0 then 1.2), RobustPrune "
+                      + ("one-stage (paper Alg. 2)" if a.paper_prune else "two-stage (DiskANN occlude_list)"), "n": n, "d": d, "R": a.R,
            "L_build": a.L, "build_s": round(build_s), "beams": {}}
     for beam in [int(x) for x in a.beams.split(",")]:
         kk, dd, cc, st = G.search_batch(Q, k, beam, 1, a.threads)

@@ -20,7 +20,7 @@ def build():
     X = po.gen_rows(SEED, 96, 32, 64, 1.0, 0, 0, 2000)
     Q = po.gen_rows(SEED, 96, 32, 64, 1.0, 1, 0, 16)
     # Vamana: sequential build (alpha 1.2), GreedySearch at two beam widths
-    V = po.Graph.build_vamana(X, R=12, L=32, alpha=1.2)
+    V = po.Graph.build_vamana(X, R=12, L=32, alpha=1.2, two_stage=False)  # the pins predate the two-stage prune
     lv, uo, a0, aU = V.export()
     out["vam_graph"] = np.array([int(a0.astype(np.uint64).sum()), V.entry, int((a0 != 0xFFFFFFFF).sum())], np.uint64)
     for L in (8, 40):

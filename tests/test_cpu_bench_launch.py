@@ -67,3 +67,39 @@ def test_gpus_2_without_a_gpu_fails_in_the_child_ranks_not_in_an_argument_check(
     assert "torch.distributed.run" in err  # the spawned command line is logged
     assert "needs a GPU" in err or "GPUs requested" in err  # said by the ranks
     assert "must be launched" not in err
+
+
+def test_default_run_reports_every_one_gpu_config_in_one_line(capsys, monkeypatch):
+    """`python bench.py --gpus 1 --steps K --warmup W` (the driver's shape): headline child first (with the caller's flags +
+    --headline-only), then one child per other 1-GPU BASELINE config; ONE line comes out, the headline's plus `other_configs`."""
+    import json
+    b = _bench()
+    args = types.SimpleNamespace(gpus=1)
+    seen = []
+
+    def run(cmd):
+        seen.append(cmd)
+        if "--headline-only" in cmd:
+            return types.SimpleNamespace(returncode=0, stdout=b'{"metric": "m", "value": 1.0, "config": {"workload": "hnsw10m"}}\n')
+        wl = cmd[cmd.index("--workload") + 1]
+        if wl == "recompute10m":
+            return types.SimpleNamespace(returncode=3, stdout=b"")
+        line = {"value": 2.0, "unit": "queries/s", "recall_at_10": 0.97, "config": {"workload": wl, "ef_search": 128},
+                "roofline": {"bound": "hbm", "frac": 0.7, "kernel": "k", "kernel_avg_ms": 1.5}}
+        return types.SimpleNamespace(returncode=0, stdout=(json.dumps(line) + "\n").encode())
+    assert b.run_all_configs(args, ["--gpus", "1", "--steps", "20", "--warmup", "5"], run=run) == 0
+    line = json.loads(capsys.readouterr().out.strip())
+    assert seen[0][-5:] == ["--steps", "20", "--warmup", "5", "--headline-only"]
+    assert line["value"] == 1.0 and set(line["other_configs"]) == {n for n, _, _ in b.OTHER_CONFIGS}
+    assert line["other_configs"]["hnsw1m_ef128"]["roofline"]["frac"] == 0.7 and line["other_configs"]["hnsw1m_ef128"]["kernel_avg_ms"] == 1.5
+    assert "failed" in line["other_configs"]["recompute10m_exhaustive_batch64"]
+    # a failing headline fails the run; nothing else is started
+    seen.clear()
+    assert b.run_all_configs(args, [], run=lambda cmd: (seen.append(cmd), types.SimpleNamespace(returncode=2, stdout=b""))[1]) == 2
+    assert len(seen) == 1
+    # out of budget: legs are named as skipped, not silently dropped
+    monkeypatch.setenv("LEANN_BENCH_BUDGET_S", "1")
+    capsys.readouterr()
+    assert b.run_all_configs(args, [], run=run) == 0
+    line = json.loads(capsys.readouterr().out.strip())
+    assert all("skipped" in v for v in line["other_configs"].values())

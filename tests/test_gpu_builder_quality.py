@@ -65,3 +65,34 @@ def test_vamana_builder_matches_sequential_quality(la, po, gpu, n, d):
         print(f"  L={ef}: recall@10 sequential {r_seq:.4f} / GPU {r_gpu:.4f}")
         assert r_gpu >= r_seq - 0.01
     s.close()
+
+
+def test_vamana_r32_stays_navigable_at_4m_rows(la, gpu):
+    """at the reference's default degree (graph_degree 32, src/cli/build.rs:79; alpha 1.2, src/backend/diskann.rs:91)
+    the round-2 builder reached recall@10 0.98 at 1M rows and 0.60 at 10M x 1536 (beam 128).  Cause: the one-stage RobustPrune of the
+    paper keeps the R nearest candidates on data of high intrinsic dimension; with DiskANN's two-stage form (build.hip:prune_core) the
+    same rows give 0.975-0.98 at 10M (profiles/r03_vamana_scale.md).  Here: 4M x 256 rows, R = 32, build beam 128, search beam 128 ->
+    recall@10 >= 0.95 (the one-stage rule measures ~0.92 at this size and fails), every node reachable from another one."""
+    n, d, R, nq, k = 4_000_000, 256, 32, 1000, 10
+    L_, chk = la.lib(), la._native.check
+    dX = la.DeviceArray((n, d), np.float32)
+    chk(L_.leann_synth_rows_device(SEED, d, d, 64, 4096, 1.0, 0, 0, n, dX.ptr, None))
+    dQ = la.DeviceArray((nq, d), np.float32)
+    chk(L_.leann_synth_rows_device(SEED, d, d, 64, 4096, 1.0, 1, 0, nq, dQ.ptr, None))
+    la.sync()
+    tk, ts, tc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    chk(L_.leann_scan_topk_device(dX.ptr, n, d, d, dQ.ptr, nq, k, None, 0, tk.ptr, ts.ptr, tc.ptr, None))
+    la.sync()
+    truth = tk.to_host()
+    s = la.BackendSearcher.build_device(la.BackendType.DiskAnn, dX.ptr, n, d, d, R, 128)
+    gk, gd, gc = la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32)
+    s.search_batch_device(dQ.ptr, nq, k, 128, gk.ptr, gd.ptr, gc.ptr)
+    la.sync()
+    rec = recall_at_k(gk.to_host(), truth)
+    adj = s.graph_export()["adj0"]
+    valid = adj != 0xFFFFFFFF
+    indeg = np.bincount(adj[valid].astype(np.int64), minlength=n)
+    print(f"vamana R=32, {n} x {d}: recall@10 {rec:.4f} at L=128, in-degree 0: {(indeg == 0).mean():.2e}, mean out-degree {valid.sum(1).mean():.2f}")
+    assert rec >= 0.95
+    assert (indeg == 0).mean() < 1e-4
+    s.close()

@@ -34,6 +34,9 @@ def index_dir(tmp_path_factory, gpu):
     docs = _docs(600)
     (d / "docs.jsonl").write_text("\n".join(json.dumps(x) for x in docs))
     r = _run("build", "--index-dir", str(d / "idx"), "--passages-jsonl", str(d / "docs.jsonl"), "--dimensions", "96",
+             "--graph-degree", "16", "--complexity", "64", "--recompute")  # --recompute: documents.embeddings is written (builder.rs:105-113)
+    assert r.returncode == 0, r.stderr
+    r = _run("build", "--index-dir", str(d / "plain"), "--passages-jsonl", str(d / "docs.jsonl"), "--dimensions", "96",
              "--graph-degree", "16", "--complexity", "64")
     assert r.returncode == 0, r.stderr
     r = _run("build", "--index-dir", str(d / "pruned"), "--passages-jsonl", str(d / "docs.jsonl"), "--dimensions", "96", "--pruned")
@@ -50,6 +53,10 @@ def test_index_directory_layout(index_dir):
     assert meta["backend_name"] == "hnsw" and meta["dimensions"] == 96 and meta["passage_count"] == 600
     assert os.path.getsize(index_dir / "idx" / "documents.embeddings") == 600 * 96 * 4
     assert "documents.index" not in os.listdir(index_dir / "pruned")  # pruned: no ANN index, recompute at query time
+    # without --recompute: no embeddings file, meta.is_recompute false — the reference's default (cli/build.rs:363, builder.rs:105-113)
+    assert "documents.embeddings" not in os.listdir(index_dir / "plain") and "documents.index" in os.listdir(index_dir / "plain")
+    assert json.loads((index_dir / "plain" / "documents.leann.meta.json").read_text())["is_recompute"] is False
+    assert meta["is_recompute"] is True
 
 
 def test_search_json_and_text(index_dir):

@@ -383,7 +383,7 @@ def test_regression_pins_v2_gpu(la, po, gpu):
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pins_v2.npz"))
     X = po.gen_rows(SEED, 96, 32, 64, 1.0, 0, 0, 2000)
     Q = po.gen_rows(SEED, 96, 32, 64, 1.0, 1, 0, 16)
-    V = po.Graph.build_vamana(X, R=12, L=32, alpha=1.2)
+    V = po.Graph.build_vamana(X, R=12, L=32, alpha=1.2, two_stage=False)  # the pins predate the two-stage prune
     lv, uo, a0, aU = V.export()
     assert int(a0.astype(np.uint64).sum()) == int(z["vam_graph"][0]) and V.entry == int(z["vam_graph"][1])
     s = la.BackendSearcher.from_arrays(la.BackendType.DiskAnn, X, 12, 12, 0, V.entry, lv, uo, a0, aU)
