@@ -490,6 +490,11 @@ def main():
     ap.add_argument("--filter-selectivity", type=float, default=0.0,
                     help="side experiment (not the headline metric): metadata-filtered search with a seeded random allow-bitmap "
                          "of this density evaluated inside the traversal; recall is measured against the exact FILTERED top-k")
+    ap.add_argument("--sigma", type=float, default=None,
+                    help="per-point noise of the synthetic corpus (default 1.0; SURVEY.md §8d wrote 0.15 — tighter clusters; the value used is in config.workload)")
+    ap.add_argument("--clusters", type=int, default=None,
+                    help="number of cluster centres of the synthetic corpus (default 4096).  65536 puts (almost) every query of a 16 384-query "
+                         "launch into a cluster of its own: bounds what queries sharing a neighbourhood gain from L2 / Infinity Cache")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the workload itself.  Without it (and without --workload) the default run measures the headline AND compact legs "
                          "of every other 1-GPU BASELINE config, each in a child process, and reports them under `other_configs` of the one line")
@@ -509,6 +514,11 @@ def main():
                          "leann_backend_search_filtered_exact_batch_device) instead of walking the graph")
     args = ap.parse_args()
 
+    global GEN_SIGMA, GEN_CLUSTERS
+    if args.sigma is not None:
+        GEN_SIGMA = float(args.sigma)
+    if args.clusters is not None:
+        GEN_CLUSTERS = int(args.clusters)
     explicit_workload = any(x == "--workload" or x.startswith("--workload=") for x in sys.argv[1:])
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not explicit_workload and not args.headline_only:
         # the driver's command shape (`python bench.py --gpus 1 --steps K --warmup W`): headline + every other 1-GPU BASELINE config.
@@ -915,7 +925,7 @@ def main():
     st = st[:used].reshape(-1, 4)
     evals, hops0, hopsU, ovf = [float(x) for x in st.sum(0)]
     nq_stat = st.shape[0]
-    row_bytes = 2 * hfeat + 8 if rgraph else d * 4  # recompute-on: 256 bf16 features + f32 norm (+pad) per evaluated neighbour
+    row_bytes = 2 * hfeat + 4 if rgraph else d * 4  # recompute-on: 256 bf16 features + the f32 norm per evaluated neighbour (round 2 counted the 520-B padded row)
     bytes_per_query = (evals * row_bytes + hops0 * gi["M0"] * 4 + hopsU * gi["M"] * 4) / nq_stat
     bytes_per_launch = bytes_per_query * B
     achieved = bytes_per_launch / kern_avg_s / 1e9
@@ -1137,6 +1147,17 @@ def main():
             t0 = time.perf_counter()
             ck, cd, cc, cs = G.search_batch(Qh, kk, ef, 0, cores)
             cpu_s = time.perf_counter() - t0
+            # second figure: the same walk with a plain 4-accumulator AVX2 dot (oracle.c:orc_dot_fast — what a SIMD
+            # library such as usearch's does) instead of the bit-exact canonical tree; timing only, never used for the identity check
+            simd = None
+            try:
+                po.lib().orc_set_fast_dot(1)
+                G.search_batch(Qh[: min(256, ncpu)], kk, ef, 0, cores)
+                t0 = time.perf_counter()
+                G.search_batch(Qh, kk, ef, 0, cores)
+                simd = ncpu / (time.perf_counter() - t0)
+            finally:
+                po.lib().orc_set_fast_dot(0)
             search(0)
             stream.synchronize()
             gk_ = keys[:ncpu].cpu().numpy().view(np.uint64)
@@ -1197,6 +1218,10 @@ def main():
                           f"one query per thread on {cores} host threads (oracle/oracle.c, AVX2 canonical dot)" + rerank_note,
                 "gpu_results_bit_identical_on_sample": same,
             }
+            if simd is not None and not rgraph:
+                out["cpu_baseline"]["simd_value"] = simd
+                out["cpu_baseline"]["simd_note"] = ("kind port-simd: the same walk on the same threads with a plain 4-accumulator AVX2 dot "
+                                                    "(not bit-compatible with the GPU; the graph walk only, no rerank); `value` uses the bit-exact canonical dot")
             if lat is not None:  # the CPU port's latency for ONE query on ONE thread, beside the GPU's single-query latency
                 tc = np.empty(min(300, ncpu))
                 for i in range(len(tc)):

@@ -188,6 +188,7 @@ static void set_pool_args(const leann_backend *h, SearchArgs &a) {
 
 void leann_internal_free_graph(leann_backend *h) {
     if (h->owns_rows) (void)hipFree((void *)h->g.X);
+    (void)hipFree((void *)h->g.norms);
     (void)hipFree((void *)h->g.adj0);
     (void)hipFree((void *)h->g.adjU);
     (void)hipFree((void *)h->g.upper_off);
@@ -743,7 +744,7 @@ static int search_filtered_batch_host_impl(const leann_backend *hc, const float 
             h->stats.n_hops_upper += hstats[i * 4 + 2];
             h->stats.n_table_overflow += hstats[i * 4 + 3] ? 1 : 0;
             n_lost += hstats[i * 4 + 3] == 3;
-            h->stats.algorithmic_bytes += (uint64_t)hstats[i * 4 + 0] * (gv.feat_h ? gv.row_bytes : d * 4) + (uint64_t)hstats[i * 4 + 1] * gv.M0 * 4 +
+            h->stats.algorithmic_bytes += (uint64_t)hstats[i * 4 + 0] * (gv.feat_h ? (gv.norms ? 2 * (size_t)gv.feat_h + 4 : (size_t)gv.row_bytes) : d * 4) + (uint64_t)hstats[i * 4 + 1] * gv.M0 * 4 +
                                           (uint64_t)hstats[i * 4 + 2] * gv.M * 4;
         }
         h->stats.n_queries += nq;
@@ -1034,9 +1035,27 @@ int leann_internal_from_host(int backend, size_t n, size_t dims, uint32_t M, uin
     const size_t nn = std::max<size_t>(n, 1), nu = std::max<size_t>(n_upper_lists, 1), ld = h->g.ld;
     if (feat) {
         h->g.feat_h = feat_h;
-        h->g.row_bytes = row_bytes;
-        if (hipMalloc((void **)&h->g.X, nn * row_bytes) != hipSuccess) return fail("hipMalloc(rows)");
-        if (n && hipMemcpy((void *)h->g.X, feat_rows, n * (size_t)row_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("upload of the feature rows");
+        if (feat_h == 256) { // split device layout (GraphView::norms): 512-B rows of whole lines, norms beside them
+            h->g.row_bytes = 512;
+            if (hipMalloc((void **)&h->g.X, nn * 512) != hipSuccess || hipMalloc((void **)&h->g.norms, nn * 4) != hipSuccess) return fail("hipMalloc(rows)");
+            const size_t slab = (size_t)1 << 20; // de-interleaved on the host, uploaded contiguously
+            std::vector<unsigned char> fr(std::min(slab, nn) * 512);
+            std::vector<float> nr(std::min(slab, nn));
+            for (size_t s0 = 0; s0 < n; s0 += slab) {
+                const size_t m = std::min(slab, n - s0);
+                for (size_t i = 0; i < m; i++) {
+                    memcpy(fr.data() + i * 512, feat_rows + (s0 + i) * row_bytes, 512);
+                    memcpy(&nr[i], feat_rows + (s0 + i) * row_bytes + 512, 4);
+                }
+                if (hipMemcpy((unsigned char *)h->g.X + s0 * 512, fr.data(), m * 512, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy((void *)(h->g.norms + s0), nr.data(), m * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    return fail("upload of the feature rows");
+            }
+        } else {
+            h->g.row_bytes = row_bytes;
+            if (hipMalloc((void **)&h->g.X, nn * row_bytes) != hipSuccess) return fail("hipMalloc(rows)");
+            if (n && hipMemcpy((void *)h->g.X, feat_rows, n * (size_t)row_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("upload of the feature rows");
+        }
         if (hipMalloc((void **)&h->Wf32, (size_t)feat_h * dims * 4) != hipSuccess) return fail("hipMalloc(weights)");
         if (hipMemcpy(h->Wf32, Wf32, (size_t)feat_h * dims * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("upload of the weights");
     } else {

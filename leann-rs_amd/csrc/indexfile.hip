@@ -81,20 +81,21 @@ int leann_internal_save_to(const leann_backend *h, const std::string &path) {
     hd.max_level = h->g.max_level; hd.entry = h->g.entry; hd.efc = h->efc; hd.alpha = h->alpha;
     hd.n_upper_lists = h->n_upper_lists;
     hd.feat_h = h->g.feat_h;
-    hd.row_bytes = h->g.row_bytes;
+    hd.row_bytes = feat ? (uint32_t)leann_internal_feat_file_row_bytes(h->g) : h->g.row_bytes;
     bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1;
     ok = ok && (n == 0 || fwrite(levels.data(), 1, n, f) == n);
     ok = ok && (n == 0 || fwrite(uo.data(), 4, n, f) == n);
     ok = ok && (n == 0 || fwrite(a0.data(), 4, n * h->g.M0, f) == n * h->g.M0);
     ok = ok && (h->n_upper_lists == 0 || fwrite(aU.data(), 4, h->n_upper_lists * h->g.M, f) == h->n_upper_lists * h->g.M);
     // rows in slabs of <= 256 MiB: a 10M x 768 index is 30 GB, more than some hosts want to hold twice
-    const size_t row_b = feat ? h->g.row_bytes : d * 4, dev_pitch = feat ? h->g.row_bytes : (size_t)h->g.ld * 4;
+    const size_t row_b = feat ? leann_internal_feat_file_row_bytes(h->g) : d * 4, dev_pitch = feat ? h->g.row_bytes : (size_t)h->g.ld * 4;
     const size_t slab_rows = std::max<size_t>(1, ((size_t)256 << 20) / std::max<size_t>(row_b, 1));
     std::vector<unsigned char> slab(std::min(slab_rows, std::max<size_t>(n, 1)) * row_b);
     for (size_t r0 = 0; ok && r0 < n; r0 += slab_rows) {
         const size_t rows = std::min(slab_rows, n - r0);
-        if (hipMemcpy2D(slab.data(), row_b, reinterpret_cast<const unsigned char *>(h->g.X) + r0 * dev_pitch, dev_pitch, row_b, rows,
-                        hipMemcpyDeviceToHost) != hipSuccess) {
+        if (feat ? leann_internal_feat_rows_to_host(h, r0, rows, slab.data()) != LEANN_OK
+                 : hipMemcpy2D(slab.data(), row_b, reinterpret_cast<const unsigned char *>(h->g.X) + r0 * dev_pitch, dev_pitch, row_b, rows,
+                               hipMemcpyDeviceToHost) != hipSuccess) {
             fclose(f);
             (void)remove(tmp.c_str());
             leann_set_error("leann_backend_save: device read failed: %s", hipGetErrorString(hipGetLastError()));

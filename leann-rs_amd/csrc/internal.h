@@ -134,5 +134,7 @@ int leann_internal_fold_candidates(const CandEmit &em, uint32_t k, uint32_t nq, 
 int leann_internal_score(const float *X, size_t rows, size_t dims, size_t ld, const float *d_queries, size_t nq, size_t ldq, float *S,
                          hipStream_t st);
 void leann_internal_free_graph(leann_backend *h);
+size_t leann_internal_feat_file_row_bytes(const GraphView &g);
+int leann_internal_feat_rows_to_host(const leann_backend *h, size_t r0, size_t rows, unsigned char *out);
 std::string leann_internal_index_file(const char *stem, int backend);
 std::string leann_internal_with_extension(const std::string &stem, const char *ext);

@@ -22,6 +22,7 @@
 #include "../../include/leann_backend.h"
 #include "internal.h"
 #include <thread>
+#include <cstring>
 #include <string>
 #include "recompute_fstat.cuh" // fused_fstat_kernel, tile_features_kernel; bf16x8 / f32x16
 #include <algorithm>
@@ -994,7 +995,32 @@ __global__ void pack_feature_rows_kernel(const uint16_t *__restrict__ F, const f
     const uint32_t e = (uint32_t)(idx % per);
     unsigned char *dst = out + row * row_bytes;
     if (e < hp4) reinterpret_cast<uint16_t *>(dst)[e] = e < h ? F[row * h + e] : (uint16_t)0;
-    else if (e == hp4) *reinterpret_cast<float *>(dst + 2 * (size_t)hp4) = norms[row];
+    else if (e == hp4 && row_bytes >= 2 * hp4 + 4) *reinterpret_cast<float *>(dst + 2 * (size_t)hp4) = norms[row]; // (split layout: no slot)
+}
+// the inline file / export form [features | f32 norm | pad] of an index whose device rows are split (GraphView::norms)
+size_t leann_internal_feat_file_row_bytes(const GraphView &g) { return g.norms ? ((2 * (size_t)g.feat_h + 4 + 7) & ~(size_t)7) : g.row_bytes; }
+int leann_internal_feat_rows_to_host(const leann_backend *h, size_t r0, size_t rows, unsigned char *out) {
+    const size_t fb = leann_internal_feat_file_row_bytes(h->g);
+    if (!h->g.norms) {
+        HIP_CHECK_RET(hipMemcpy(out, reinterpret_cast<const unsigned char *>(h->g.X) + r0 * h->g.row_bytes, rows * fb, hipMemcpyDeviceToHost));
+        return LEANN_OK;
+    }
+    // contiguous device reads, interleaved on the host (a 2-D copy of 4-byte columns is one tiny DMA per row)
+    const size_t fw = 2 * (size_t)h->g.feat_h, slab = (size_t)1 << 20;
+    std::vector<unsigned char> fr(std::min(slab, std::max<size_t>(rows, 1)) * fw);
+    std::vector<float> nr(std::min(slab, std::max<size_t>(rows, 1)));
+    for (size_t s0 = 0; s0 < rows; s0 += slab) {
+        const size_t m = std::min(slab, rows - s0);
+        HIP_CHECK_RET(hipMemcpy(fr.data(), reinterpret_cast<const unsigned char *>(h->g.X) + (r0 + s0) * h->g.row_bytes, m * fw, hipMemcpyDeviceToHost));
+        HIP_CHECK_RET(hipMemcpy(nr.data(), h->g.norms + r0 + s0, m * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < m; i++) {
+            unsigned char *dst = out + (s0 + i) * fb;
+            memcpy(dst, fr.data() + i * fw, fw);
+            memcpy(dst + fw, &nr[i], 4);
+            memset(dst + fw + 4, 0, fb - fw - 4);
+        }
+    }
+    return LEANN_OK;
 }
 __global__ void bf16_to_f32_kernel(const uint16_t *__restrict__ in, size_t n, float *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1026,7 +1052,8 @@ extern "C" int leann_recompute_build_index(const leann_recompute *r, int backend
     if (rc != LEANN_OK) { (void)hipFree(E); (void)hipFree(norms); return rc; }
     // swap the rows: features + inline norm replace the embeddings
     const uint32_t hp4 = (uint32_t)((r->h + 3) & ~(size_t)3);
-    const uint32_t row_bytes = (2 * hp4 + 4 + 7) & ~7u;
+    const bool split = hp4 == 256; // 512-B rows of whole lines + the norms in an array of their own (GraphView::norms)
+    const uint32_t row_bytes = split ? 2 * hp4 : (2 * hp4 + 4 + 7) & ~7u;
     unsigned char *rows_b = nullptr;
     HIP_CHECK_RET(hipMalloc((void **)&rows_b, std::max<size_t>(n, 1) * row_bytes));
     HIP_CHECK_RET(hipMemset(rows_b, 0, std::max<size_t>(n, 1) * row_bytes));
@@ -1040,7 +1067,8 @@ extern "C" int leann_recompute_build_index(const leann_recompute *r, int backend
     HIP_CHECK_RET(hipGetLastError());
     HIP_CHECK_RET(hipDeviceSynchronize());
     (void)hipFree(E);
-    (void)hipFree(norms);
+    if (split) h->g.norms = norms; // (freed with the graph)
+    else (void)hipFree(norms);
     h->g.X = reinterpret_cast<const float *>(rows_b);
     h->owns_rows = true;
     h->g.feat_h = hp4;
@@ -1053,7 +1081,7 @@ extern "C" int leann_recompute_build_index(const leann_recompute *r, int backend
 extern "C" int leann_backend_feature_rows_export(const leann_backend *h, uint32_t *feat_h, uint32_t *row_bytes, void *out) {
     if (!h || !h->g.feat_h) { leann_set_error("not a recompute-on index"); return LEANN_ERR_INVALID; }
     if (feat_h) *feat_h = h->g.feat_h;
-    if (row_bytes) *row_bytes = h->g.row_bytes;
-    if (out) HIP_CHECK_RET(hipMemcpy(out, h->g.X, (size_t)h->g.n * h->g.row_bytes, hipMemcpyDeviceToHost));
+    if (row_bytes) *row_bytes = (uint32_t)leann_internal_feat_file_row_bytes(h->g); // the inline form, whatever the device layout
+    if (out) return leann_internal_feat_rows_to_host(h, 0, (size_t)h->g.n, static_cast<unsigned char *>(out));
     return LEANN_OK;
 }

@@ -34,6 +34,11 @@ struct GraphView {
     // [feat_h bf16 features][f32 ||W^T f||][pad], `row_bytes` apart; the query side is g = W q (feat_h f32) and
     // dist = 1 - <f, g> / ||W^T f||  ==  1 - <l2norm(W^T f), q>.  feat_h == 0: plain f32 rows.
     uint32_t feat_h, row_bytes;
+    // Rows of exactly 256 features live SPLIT on the device: X = [n x 512 B] of features (row_bytes = 512: every row is four whole,
+    // aligned 128-B lines) and `norms` = [n] f32.  With the norm inline a 520-B row touches 5.06 lines on average — 20 % of the
+    // fabric traffic was padding (PMC 1.20 x the algorithmic bytes, profiles/r02_other_kernels.md).  Files, exports and the oracle keep
+    // the inline form (interleaved on the way out); null: inline norm behind the features.
+    const float *norms;
 };
 
 // Pools of visited tables in HBM for the rare query whose LDS table fills up.  Pool 1: GPOOL_TABLES tables of
@@ -143,7 +148,8 @@ __device__ __forceinline__ void wave_dist_rows(const float4 (&q)[T], const float
 // (one 8-byte load per chunk), so the canonical accumulation order is unchanged; only the operands differ.
 template <int T, int R>
 __device__ __forceinline__ void wave_dist_rows_feat(const float4 (&q)[T], const char *__restrict__ Xb, uint32_t row_bytes,
-                                                    uint32_t h, const uint32_t (&ids)[R], int nrows, int lane, float (&out)[R]) {
+                                                    uint32_t h, const uint32_t (&ids)[R], int nrows, int lane, float (&out)[R],
+                                                    const float *__restrict__ norms = nullptr) {
     uint2 v[R][T];
     float nrm[R];
 #pragma unroll
@@ -155,7 +161,7 @@ __device__ __forceinline__ void wave_dist_rows_feat(const float4 (&q)[T], const 
                 const uint32_t j = 256u * t + 4u * lane;
                 v[r][t] = j < h ? *reinterpret_cast<const uint2 *>(row + 2 * (size_t)j) : make_uint2(0u, 0u);
             }
-            nrm[r] = *reinterpret_cast<const float *>(row + 2 * (size_t)h);
+            nrm[r] = norms ? norms[ids[r]] : *reinterpret_cast<const float *>(row + 2 * (size_t)h);
         }
     }
 #pragma unroll
@@ -199,7 +205,7 @@ __device__ __forceinline__ float feat8_partial_pair(const float (&q)[8], const u
 template <int G>
 __device__ __forceinline__ void group_dist_rows_feat256(const float (&qa)[8], const float (&qb)[8], const char *__restrict__ Xb,
                                                         uint32_t row_bytes, const uint32_t (&id)[G], const bool (&valid)[G], int lane,
-                                                        float (&out)[G]) {
+                                                        float (&out)[G], const float *__restrict__ norms) {
     const int m = lane & 15;
     u32x4_a8 va[G], vb[G];
     float nrm[G];
@@ -211,7 +217,7 @@ __device__ __forceinline__ void group_dist_rows_feat256(const float (&qa)[8], co
             const char *row = Xb + (size_t)id[g] * row_bytes;
             va[g] = *reinterpret_cast<const u32x4_a8 *>(row + 16 * m);
             vb[g] = *reinterpret_cast<const u32x4_a8 *>(row + 256 + 16 * m);
-            if (m == 15) nrm[g] = *reinterpret_cast<const float *>(row + 512);
+            if (m == 15) nrm[g] = norms ? norms[id[g]] : *reinterpret_cast<const float *>(row + 512);
         }
     }
 #pragma unroll
@@ -317,9 +323,9 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
         float dd[1];
         if (G16) {
             const bool valid[1] = {lane < 16};
-            group_dist_rows_feat256<1>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd);
+            group_dist_rows_feat256<1>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd, g.norms);
             dd[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dd[0]), 15));
-        } else if (FEAT) wave_dist_rows_feat<T, 1>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, 1, lane, dd);
+        } else if (FEAT) wave_dist_rows_feat<T, 1>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, 1, lane, dd, g.norms);
         else wave_dist_rows<T, 1>(q, g.X, g.ld, ids, 1, lane, dd);
         best = make_key(dd[0], g.entry); // every wave computes the same value
     }
@@ -477,7 +483,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                             ids[r] = valid[r] ? s.s_new[jj[r]] : 0u;
                             abyte[r] = (filt_level && valid[r] && (lane & 15) == 15) ? allow[ids[r] >> 3] : 0u;
                         }
-                        group_dist_rows_feat256<R>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd);
+                        group_dist_rows_feat256<R>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd, g.norms);
                         if ((lane & 15) == 15) {
     #pragma unroll
                             for (int r = 0; r < R; r++)
@@ -504,7 +510,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                         abyte = allow[e >> 3];
                         abit = e & 7u;
                     }
-                    if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd);
+                    if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd, g.norms);
                     else wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
                     const unsigned long long amask = FILT ? __ballot((abyte >> abit) & 1u) : 0ull;
                     if (lane == 0) {
@@ -763,7 +769,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                         if (lv == 0 && valid[0] && (lane & 14) == 12 && (uint32_t)(lane & 1) * 32u < deg)
                             touch = adj0_p[(size_t)ids[0] * deg + (uint32_t)(lane & 1) * 32u];
 #endif
-                        group_dist_rows_feat256<R>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd);
+                        group_dist_rows_feat256<R>(qa, qb, reinterpret_cast<const char *>(g.X), g.row_bytes, ids, valid, lane, dd, g.norms);
 #ifndef LEANN_NO_ADJ_TOUCH
                         asm volatile("" ::"v"(touch));
 #endif
@@ -803,7 +809,7 @@ __device__ void beam_search_one(const GraphView &g, const SearchArgs &a, uint32_
                     if (lv == 0 && (uint32_t)(lane >> 1) < (uint32_t)nrows && (uint32_t)(lane & 1) * 32u < deg)
                         touch = adj0_p[(size_t)snew[j0 + (uint32_t)(lane >> 1) * NW] * deg + (uint32_t)(lane & 1) * 32u];
 #endif
-                    if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd);
+                    if (FEAT) wave_dist_rows_feat<T, R>(q, reinterpret_cast<const char *>(g.X), g.row_bytes, g.feat_h, ids, nrows, lane, dd, g.norms);
                     else wave_dist_rows<T, R>(q, g.X, g.ld, ids, nrows, lane, dd);
 #ifndef LEANN_NO_ADJ_TOUCH
                     asm volatile("" ::"v"(touch));

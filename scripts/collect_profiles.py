@@ -1,9 +1,10 @@
-"""Turns the outputs of scripts/regen_profiles.sh, profile_headline.sh and profile_side.sh (gpurun_out/r02/) into the committed
-profiles/r02_* files: bench lines, rocprofv3 kernel-stats CSVs, the PMC traffic JSON bench.py quotes, and r02_headline_profile.md."""
+"""Turns the outputs of scripts/regen_profiles.sh, profile_headline.sh and profile_side.sh (gpurun_out/<ROUND>/) into the committed
+profiles/<ROUND>_* files: bench lines, rocprofv3 kernel-stats CSVs, the PMC traffic JSON bench.py quotes, and <ROUND>_headline_profile.md."""
 import csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst = os.path.join(ROOT, "gpurun_out", "r02"), os.path.join(ROOT, "profiles")
+ROUND = os.environ.get("ROUND", "r03")  # outputs of the round's runs live under gpurun_out/<ROUND>/, committed copies are profiles/<ROUND>_*
+src, dst = os.path.join(ROOT, "gpurun_out", ROUND), os.path.join(ROOT, "profiles")
 
 
 def last_n(path, name, n):
@@ -14,30 +15,30 @@ def last_n(path, name, n):
 
 def main():
     for f in sorted(glob.glob(os.path.join(src, "*_bench.json"))):
-        shutil.copy(f, os.path.join(dst, "r02_" + os.path.basename(f)))
+        shutil.copy(f, os.path.join(dst, ROUND + "_" + os.path.basename(f)))
     for a, b in (("r2_gather_bw.txt", "r02_gather_ceiling.txt"), ("r2_stamps_feat.txt", "r02_stamps_feat.txt")):
         p = os.path.join(ROOT, "gpurun_out", a)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, b))
     for wl in ("recompute10m_graph", "recompute10m"):
-        p = os.path.join(src, f"prof_{wl}", "r02_kernel_stats.csv")
+        p = os.path.join(src, f"prof_{wl}", ROUND + "_kernel_stats.csv")
         if os.path.exists(p):
-            shutil.copy(p, os.path.join(dst, f"r02_{wl}_kernel_stats.csv"))
-    st_path = os.path.join(src, "prof_stats", "r02_kernel_stats.csv")
+            shutil.copy(p, os.path.join(dst, f"{ROUND}_{wl}_kernel_stats.csv"))
+    st_path = os.path.join(src, "prof_stats", ROUND + "_kernel_stats.csv")
     if not os.path.exists(st_path):
-        print("no headline profile under gpurun_out/r02/prof_stats")
+        print(f"no headline profile under gpurun_out/{ROUND}/prof_stats")
         return
-    shutil.copy(st_path, os.path.join(dst, "r02_hnsw10m_kernel_stats.csv"))
+    shutil.copy(st_path, os.path.join(dst, ROUND + "_hnsw10m_kernel_stats.csv"))
     stats = list(csv.DictReader(open(st_path)))
-    trace = [r for r in csv.DictReader(open(os.path.join(src, "prof_stats", "r02_kernel_trace.csv"))) if "beam_search_kernel<3, 4, 4, false>" in r["Kernel_Name"]]
+    trace = [r for r in csv.DictReader(open(os.path.join(src, "prof_stats", ROUND + "_kernel_trace.csv"))) if "beam_search_kernel<3, 4, 4, false>" in r["Kernel_Name"]]
     trace.sort(key=lambda r: int(r["Dispatch_Id"]))
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in trace[-20:]]
     b = json.load(open(os.path.join(src, "prof_stats.json")))
     bf = json.load(open(os.path.join(src, "prof_FETCH_SIZE.json")))
-    fe = sum(last_n(os.path.join(src, "prof_FETCH_SIZE", "r02_counter_collection.csv"), "FETCH_SIZE", 4)) / 4 * 1024
-    wr = sum(last_n(os.path.join(src, "prof_WRITE_SIZE", "r02_counter_collection.csv"), "WRITE_SIZE", 4)) / 4 * 1024
-    hit = sum(last_n(os.path.join(src, "prof_TCC_HIT_sum_TCC_MISS_sum", "r02_counter_collection.csv"), "TCC_HIT_sum", 4)) / 4
-    miss = sum(last_n(os.path.join(src, "prof_TCC_HIT_sum_TCC_MISS_sum", "r02_counter_collection.csv"), "TCC_MISS_sum", 4)) / 4
+    fe = sum(last_n(os.path.join(src, "prof_FETCH_SIZE", ROUND + "_counter_collection.csv"), "FETCH_SIZE", 4)) / 4 * 1024
+    wr = sum(last_n(os.path.join(src, "prof_WRITE_SIZE", ROUND + "_counter_collection.csv"), "WRITE_SIZE", 4)) / 4 * 1024
+    hit = sum(last_n(os.path.join(src, "prof_TCC_HIT_sum_TCC_MISS_sum", ROUND + "_counter_collection.csv"), "TCC_HIT_sum", 4)) / 4
+    miss = sum(last_n(os.path.join(src, "prof_TCC_HIT_sum_TCC_MISS_sum", ROUND + "_counter_collection.csv"), "TCC_MISS_sum", 4)) / 4
     alg = bf["roofline"]["algorithmic_bytes_per_launch"]
     ef = b["config"]["ef_search"]
     assert ef == bf["config"]["ef_search"]
@@ -53,7 +54,7 @@ def main():
               open(os.path.join(dst, "pmc_traffic_hnsw10m.json"), "w"), indent=1)
     q = [r for r in stats if "beam_search_kernel<3, 4, 4, false>" in r["Name"]][0]
     rd = ""
-    p = os.path.join(src, "prof_rdreq", "r02_counter_collection.csv")
+    p = os.path.join(src, "prof_rdreq", ROUND + "_counter_collection.csv")
     if os.path.exists(p):
         try:
             a1 = sum(last_n(p, "TCC_EA0_RDREQ_sum", 4)) / 4
@@ -64,13 +65,13 @@ def main():
             rd = f"| TCC_EA0_RDREQ pass | failed: {e} |\n"
     cm = open(os.path.join(src, "counters_mem.txt")).read() if os.path.exists(os.path.join(src, "counters_mem.txt")) else ""
     import re
-    mall = "none (no counter name contains MALL; the TCC_EA0_* family stops at the L2's memory-side interface)" if not re.search(r"Counter_Name\s*:\s*\S*MALL", cm, re.I) else "present: see gpurun_out/r02/counters_mem.txt"
-    md = f"""# Round 2 profile — bench.py default workload (hnsw10m, efc={b['config']['ef_construction']}, --ef auto -> ef={ef}), 1x MI355X
+    mall = "none (no counter name contains MALL; the TCC_EA0_* family stops at the L2's memory-side interface)" if not re.search(r"Counter_Name\s*:\s*\S*MALL", cm, re.I) else "present: see gpurun_out/{ROUND}/counters_mem.txt"
+    md = f"""# {ROUND} profile — bench.py default workload (hnsw10m, efc={b['config']['ef_construction']}, --ef auto -> ef={ef}), 1x MI355X
 
-Commands (GPU box, `scripts/profile_headline.sh`): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d … -o r02 -- python3 bench.py --no-cpu-baseline --no-latency`,
+Commands (GPU box, `scripts/profile_headline.sh`): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d … -o {ROUND} -- python3 bench.py --headline-only --no-cpu-baseline --no-latency`,
 then separate `--pmc` passes (`FETCH_SIZE`; `WRITE_SIZE`; `TCC_HIT_sum TCC_MISS_sum`) of `bench.py --no-cpu-baseline --no-latency --steps 4 --warmup 1`
 with `--kernel-include-regex beam_search_kernel`.
-Files: `r02_hnsw10m_kernel_stats.csv` (every kernel of the process incl. index construction), `pmc_traffic_hnsw10m.json`, `r02_hnsw10m_bench.json` (un-profiled line).
+Files: `{ROUND}_hnsw10m_kernel_stats.csv` (every kernel of the process incl. index construction), `pmc_traffic_hnsw10m.json`, `{ROUND}_hnsw10m_bench.json` (un-profiled line).
 
 ## Dominant kernel of the timed region: `beam_search_kernel<3, 4, 4, false>`
 
@@ -92,16 +93,16 @@ Files: `r02_hnsw10m_kernel_stats.csv` (every kernel of the process incl. index c
 """
     for r in stats[:6]:
         md += f"* `{r['Name'][:60]}`: {r['Calls']} calls, {float(r['TotalDurationNs']) / 1e9:.2f} s ({r['Percentage']} %)\n"
-    open(os.path.join(dst, "r02_headline_profile.md"), "w").write(md)
+    open(os.path.join(dst, ROUND + "_headline_profile.md"), "w").write(md)
     print(md)
     other_kernels()
 
 
 def other_kernels():
     """profiles/r02_other_kernels.md: the kernels of the side workloads (scripts/profile_side.sh)"""
-    lines = ["# Round 2 — other kernels (1x MI355X; rocprofv3 --kernel-trace --stats of `bench.py --workload … --no-cpu-baseline --no-latency`)", ""]
+    lines = ["# {ROUND} — other kernels (1x MI355X; rocprofv3 --kernel-trace --stats of `bench.py --workload … --no-cpu-baseline --no-latency`)", ""]
     for wl, pat in (("recompute10m_graph", "beam_search_feat256_kernel"), ("recompute10m", "fused_fstat_kernel")):
-        pj, pc = os.path.join(src, f"prof_{wl}.json"), os.path.join(src, f"prof_{wl}", "r02_kernel_stats.csv")
+        pj, pc = os.path.join(src, f"prof_{wl}.json"), os.path.join(src, f"prof_{wl}", ROUND + "_kernel_stats.csv")
         if not (os.path.exists(pj) and os.path.exists(pc)):
             continue
         j = json.load(open(pj))
@@ -112,7 +113,7 @@ def other_kernels():
         for x in rows:
             lines.append(f"* kernel-stats row `{x['Name'][:60]}`: Calls {x['Calls']}, AverageNs {float(x['AverageNs']):.0f}, MinNs {x['MinNs']}, MaxNs {x['MaxNs']}")
         if wl == "recompute10m_graph":
-            pf, pw = (os.path.join(src, f"prof_rg_{c}", "r02_counter_collection.csv") for c in ("FETCH_SIZE", "WRITE_SIZE"))
+            pf, pw = (os.path.join(src, f"prof_rg_{c}", ROUND + "_counter_collection.csv") for c in ("FETCH_SIZE", "WRITE_SIZE"))
             if os.path.exists(pf) and os.path.exists(pw):
                 try:
                     bf = json.load(open(os.path.join(src, "prof_rg_FETCH_SIZE.json")))
@@ -135,13 +136,13 @@ def other_kernels():
             lines.append(f"* bench.py HIP-event average of the timed launches: {r['kernel_avg_ms']:.3f} ms; algorithmic bytes per query {r['algorithmic_bytes_per_query']:.0f} "
                          f"({r['dist_evals_per_query']:.0f} evaluations x 520 B + {r['hops_per_query']:.0f} hops x 256 B); ceiling for random 520-B rows read four per instruction: 10 G rows/s = 5.2 TB/s algorithmic = 6.4 TB/s in whole 128-B lines (`r02_gather_ceiling.txt`)")
         lines.append("")
-    pm = os.path.join(src, "prof_mfma", "r02_counter_collection.csv")
+    pm = os.path.join(src, "prof_mfma", ROUND + "_counter_collection.csv")
     if os.path.exists(pm):
         busy, act = last_n(pm, "SQ_VALU_MFMA_BUSY_CYCLES", 1)[0], last_n(pm, "GRBM_GUI_ACTIVE", 1)[0]
         lines += ["## fused_fstat_kernel matrix-pipe utilisation (separate `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass, the 9.5M-row launch of a step)", "",
                   f"* SQ_VALU_MFMA_BUSY_CYCLES = {busy:.4e}, GRBM_GUI_ACTIVE = {act:.4e} summed over 8 XCDs -> MfmaUtil = busy / (active / 8 x 1024 SIMDs) = "
                   f"**{busy / (act / 8 * 1024) * 100:.1f} %** of the resident cycles (round 1: 72.6 %)", ""]
-    pr = os.path.join(src, "prof_rdreq", "r02_counter_collection.csv")
+    pr = os.path.join(src, "prof_rdreq", ROUND + "_counter_collection.csv")
     if os.path.exists(pr):
         a1, a2 = sum(last_n(pr, "TCC_EA0_RDREQ_sum", 4)) / 4, sum(last_n(pr, "TCC_EA0_RDREQ_DRAM_sum", 4)) / 4
         lines += ["## hnsw10m: where the L2's read requests go (`--pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum`)", "",
@@ -149,12 +150,12 @@ def other_kernels():
                   "Cache sits behind that interface and no counter of it is exposed on this pool", ""]
     fs = os.path.join(src, "forced_shard_rccl_world1.json")
     if os.path.exists(fs):
-        open(os.path.join(dst, "r02_forced_shard_rccl_world1.json"), "w").write([l for l in open(fs) if l.startswith("{")][-1])
+        open(os.path.join(dst, ROUND + "_forced_shard_rccl_world1.json"), "w").write([l for l in open(fs) if l.startswith("{")][-1])
         j = json.loads([l for l in open(fs) if l.startswith("{")][-1])
         lines += ["## The N > 1 code path of bench.py with one rank (`LEANN_BENCH_FORCE_SHARD=1 python -m torch.distributed.run --nproc-per-node 1 … bench.py --workload hnsw100k`)", "",
                   f"* shard mode through the library's RCCL group (ncclCommInitRank + ncclAllGather + merge kernel, tickets): {j['value']:.0f} queries/s, recall@10 {j['recall_at_10']:.4f}; "
                   f"`{j['config'].get('value_unit_note', '')}`", ""]
-    open(os.path.join(dst, "r02_other_kernels.md"), "w").write("\n".join(lines))
+    open(os.path.join(dst, ROUND + "_other_kernels.md"), "w").write("\n".join(lines))
 
 
 if __name__ == "__main__":

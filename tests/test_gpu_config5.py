@@ -112,7 +112,7 @@ def diskann_dir(tmp_path_factory, gpu):
     d = tmp_path_factory.mktemp("config5")
     (d / "docs.jsonl").write_text("\n".join(json.dumps(x) for x in FX["corpus"]))
     r = _run("build", "--index-dir", str(d / "idx"), "--passages-jsonl", str(d / "docs.jsonl"), "--dimensions", str(DIMS),
-             "--backend-name", "diskann", "--graph-degree", "16", "--complexity", "64")
+             "--backend-name", "diskann", "--graph-degree", "16", "--complexity", "64", "--recompute")  # (documents.embeddings is read below)
     assert r.returncode == 0, r.stderr
     return d / "idx"
 

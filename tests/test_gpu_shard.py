@@ -239,10 +239,14 @@ def test_sharded_handle_filters_save_and_export(la, po, gpu, G, tmp_path):
     assert all((a == b).all() for a, b in zip(got, big))
     # the walk with a registered filter == per-shard filtered walks merged (the per-call bitmap path of the existing test)
     wk, wd, wc, _ = _per_shard_reference(la, po, X, Q, k, ef, G, M, lows, allow=dense)
-    for mode in ("walk", "auto"):  # 30 % allowed: the planner walks
-        gk, gd, gc = s.search_filter_batch(Q, k, ef, f_dense, mode=mode)
-        assert (gk == wk).all() and (gd == wd).all() and (gc == wc).all(), mode
-    for f in (f_sparse, f_dense, f1):
+    gk, gd, gc = s.search_filter_batch(Q, k, ef, f_dense, mode="walk")
+    assert (gk == wk).all() and (gd == wd).all() and (gc == wc).all()
+    # mode "auto" is ONE decision for the whole handle (here: 2 650 allowed rows <= 64k -> exact), the unsharded handle's decision
+    f1d = one.register_filter(dense)
+    got = s.search_filter_batch(Q, k, ef, f_dense, mode="auto")
+    assert all((a == b).all() for a, b in zip(got, one.search_filter_batch(Q, k, ef, f1d, mode="auto")))
+    assert all((a == b).all() for a, b in zip(got, one.search_filtered_exact_batch(Q, k, dense)))
+    for f in (f_sparse, f_dense, f1, f1d):
         f.close()
     # per-shard export; save -> one self-contained file per shard -> open with G devices loads them (no rebuild: same graphs, same answers)
     assert s.n_shards() == G and one.n_shards() == 0
