@@ -291,7 +291,7 @@ int leann_hybrid_rerank_device(const uint64_t *d_keys, const float *d_dists, con
  * One process, G devices: the composite handle leann_backend_open returns for a device list, or built here from rows / handles.
  * Every leann_backend_search* entry point works on it: the in-traversal allow-bitmap, exact filtered search and registered filters
  * (the bitmap is sliced per shard — interior shard boundaries are multiples of 64 —, every shard answers for its slice, lists are merged
- * by (dist, key): the same answer as an unsharded index gives for exact searches).  leann_backend_save writes one self-contained file
+ * by (dist, key): the answer of an unsharded index for exact searches, up to the order of entries with equal distances).  leann_backend_save writes one self-contained file
  * per shard, "<stem>.shard<g>of<G>.index" / ".diskann", which leann_backend_open with a list of G devices loads again; graph export is
  * per shard (leann_backend_shard).  Queries and results of the *_device calls live on the first device of the list.
  * One process per GPU: leann_sharded_attach joins this rank's shard to an RCCL communicator (librccl.so is resolved at run time);

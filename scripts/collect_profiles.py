@@ -100,7 +100,7 @@ Files: `{ROUND}_hnsw10m_kernel_stats.csv` (every kernel of the process incl. ind
 
 def other_kernels():
     """profiles/r02_other_kernels.md: the kernels of the side workloads (scripts/profile_side.sh)"""
-    lines = ["# {ROUND} — other kernels (1x MI355X; rocprofv3 --kernel-trace --stats of `bench.py --workload … --no-cpu-baseline --no-latency`)", ""]
+    lines = [f"# {ROUND} — other kernels (1x MI355X; rocprofv3 --kernel-trace --stats of `bench.py --workload … --no-cpu-baseline --no-latency`)", ""]
     for wl, pat in (("recompute10m_graph", "beam_search_feat256_kernel"), ("recompute10m", "fused_fstat_kernel")):
         pj, pc = os.path.join(src, f"prof_{wl}.json"), os.path.join(src, f"prof_{wl}", ROUND + "_kernel_stats.csv")
         if not (os.path.exists(pj) and os.path.exists(pc)):
