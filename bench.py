@@ -8,7 +8,14 @@ A "step" is one pass of the hot path over one batch of synthetic queries:
     merge kernel when --gpus > 1, mode "shard").
 Inputs (corpus rows, graph, queries) are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU):
+Without --workload (the driver's command shape) and N = 1: the headline workload runs first (a child process, --headline-only), then
+compact legs of every other 1-GPU BASELINE config — configs[1] hnsw1m at ef = 128, configs[2] exhaustive recompute and the
+recompute-on graph (throughput batch and batch 64), configs[4] DiskANN R = 32 at 1536-d WITH the hybrid leg — each its own process,
+and ONE line comes out: the headline's plus `other_configs` (LEANN_BENCH_BUDGET_S bounds the whole run, default 420 s).
+--hybrid (graph workloads): every step is search(fetch_k = 5 k) + BM25 injection + hybrid_rerank on the device (csrc/hybrid.hip).
+
+N > 1: `python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N ... bench.py` itself as a child process
+(falling back to --mode composite: one process, N devices behind one handle); under a launcher it is one rank per GPU:
   mode shard   (default, north_star): the corpus is partitioned, every rank holds `rows` vectors
                (weak scaling: corpus = N x rows) with its own graph, all ranks search the same query
                batch, per-shard top-k lists are all-gathered over RCCL and merged on every rank — all
@@ -420,13 +427,23 @@ def summarise_leg(j):
     """what `other_configs` keeps of a leg's own JSON line"""
     r = j.get("roofline", {})
     o = {"value": j.get("value"), "unit": j.get("unit"), "recall_at_10": j.get("recall_at_10"), "ms_per_step": j.get("ms_per_step"),
-         "steps": j.get("steps"), "workload": j.get("config", {}).get("workload"), "ef_search": j.get("config", {}).get("ef_search"),
+         "steps": j.get("steps"), "ef_search": j.get("config", {}).get("ef_search"),
          "index_build_s": j.get("config", {}).get("index_build_s"),
          "roofline": {"bound": r.get("bound"), "frac": r.get("frac"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit")},
-         "kernel": r.get("kernel"), "kernel_avg_ms": r.get("kernel_avg_ms", r.get("fused_encode_score_ms"))}
-    for key in ("small_batch", "hybrid", "cpu_baseline"):
-        if key in j:
-            o[key] = j[key]
+         "kernel": (r.get("kernel") or "").split(" (")[0], "kernel_avg_ms": r.get("kernel_avg_ms", r.get("fused_encode_score_ms"))}
+    # numbers only: the explanatory strings live in the leg's own line (`command` reproduces it); the one line stays a few KB
+    if "small_batch" in j:
+        o["small_batch"] = {k: j["small_batch"].get(k) for k in ("batch", "ms_per_call", "value", "hbm_frac")}
+    if "hybrid" in j:
+        h = j["hybrid"]
+        o["hybrid"] = {k: h.get(k) for k in ("fetch_k", "alpha", "compat_polarity", "rerank_avg_ms", "traversal_avg_ms")}
+        o["hybrid"]["rerank_on"] = "device"
+        if "rerank_parity" in h:
+            o["hybrid"]["parity_sample"] = h["rerank_parity"].get("sample")
+            o["hybrid"]["parity_mismatches"] = h["rerank_parity"].get("mismatching_queries")
+    if "cpu_baseline" in j:
+        c = j["cpu_baseline"]
+        o["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "gpu_results_bit_identical_on_sample") if k in c}
     return o
 
 

@@ -519,7 +519,8 @@ extern "C" void leann_backend_filter_free(leann_filter *f) {
 }
 extern "C" int leann_backend_search_filter_batch(const leann_backend *hc, const float *queries, size_t nq, size_t top_k, size_t complexity,
                                                  const leann_filter *filter, int mode, uint64_t *keys, float *dists, uint32_t *counts) {
-    if (!filter || !hc || filter->n != hc->g.n || filter->device != hc->device || mode < FILTER_WALK || mode > FILTER_AUTO) {
+    if (!filter || !hc || filter->n != hc->g.n || filter->device != hc->device || mode < FILTER_WALK || mode > FILTER_AUTO ||
+        filter->parts.empty() != (hc->sharded == nullptr)) { // (a filter registered on a sharded handle holds one sub-filter per shard, and only those)
         leann_set_error("leann_backend_search_filter_batch: null / foreign filter (made for %zu rows, the index has %zu) or bad mode %d",
                         filter ? filter->n : (size_t)0, hc ? (size_t)hc->g.n : (size_t)0, mode);
         return LEANN_ERR_INVALID;

@@ -317,9 +317,17 @@ static int rows_source(const char *stem, int backend, size_t dims, std::string *
 // shards written by leann_backend_save on a composite handle: all G files present and loadable -> the index, no rebuild
 static int saved_shards(const char *stem, int backend, size_t dims, const std::vector<int> &devs, std::vector<leann_backend *> *hs) {
     const size_t G = devs.size();
-    struct stat st{};
-    for (size_t g = 0; g < G; g++)
+    struct stat st{}, so{};
+    // an index file written AFTER the shards (leann_backend_build / leann_backend_add on the same stem, i.e. `leann build --force` or
+    // `leann update`) makes them stale: they are ignored, the rows are partitioned afresh
+    const bool have_own = stat(leann_internal_index_file(stem, backend).c_str(), &so) == 0;
+    for (size_t g = 0; g < G; g++) {
         if (stat(shard_file(stem, g, G, backend, false).c_str(), &st) != 0) return LEANN_ERR_NOT_FOUND;
+        if (have_own && so.st_mtime > st.st_mtime) {
+            leann_log(LEANN_LOG_WARN, "ignoring saved shard files of %s: the index file is newer", stem);
+            return LEANN_ERR_NOT_FOUND;
+        }
+    }
     uint64_t lo = 0;
     for (size_t g = 0; g < G; g++) {
         std::string why;

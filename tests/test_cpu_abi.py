@@ -125,3 +125,21 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu(la):
     if la.device_count() == 0:
         rc = L.leann_recompute_create_host(F.ctypes.data_as(u16p), 4, 16, W.ctypes.data_as(u16p), 8, 0, 0, C.byref(out))
         assert rc == 4 and b"no CPU fallback" in L.leann_last_error()
+
+
+def test_round3_entry_points_reject_bad_arguments_without_a_gpu(la):
+    """hybrid rerank, sharded recompute, shard accessors, the knob reload hook: argument errors are LEANN_ERR_INVALID with a message;
+    nothing computes on the CPU."""
+    L = la.lib()
+    assert L.leann_hybrid_rerank_device(None, None, None, 4, 50, None, None, None, 64, 1000, 0.7, 1, 10, None, None, None, None) == 1
+    assert b"null" in L.leann_last_error()
+    out = C.c_void_p()
+    assert L.leann_recompute_create_sharded(None, 2, C.byref(out)) == 1 and not out.value
+    assert L.leann_backend_shard_count(None) == 0
+    assert L.leann_backend_shard(None, 0, C.byref(out)) == 1 and b"null" in L.leann_last_error()
+    os.environ["LEANN_HNSW_REFERENCE_EF"] = "1"
+    try:
+        L.leann_debug_reload_env()  # reads the environment again; no device needed
+    finally:
+        del os.environ["LEANN_HNSW_REFERENCE_EF"]
+        L.leann_debug_reload_env()
