@@ -902,6 +902,11 @@ extern "C" int leann_backend_add(int backend, const float *vectors, size_t n, si
     int rc = leann_backend_open(index_path_stem, backend, dims, "0", &old);
     if (rc) return rc;
     const size_t n_old = old->g.n;
+    if (old->g.feat_h) { // a recompute-on index holds encoder inputs, not vectors: appending needs the passages' features, not their embeddings
+        leann_set_error("add_to_index: this index stores no vectors (recompute-on); rebuild it from the encoder inputs (leann_recompute_build_index)");
+        leann_backend_close(old);
+        return LEANN_ERR_UNSUPPORTED;
+    }
     if (start_id != n_old) { // keys are positions (hnsw.rs:178-179): appended ids must continue the sequence
         leann_set_error("add_to_index: start_id %zu does not continue the index (%zu vectors)", start_id, n_old);
         leann_backend_close(old);
