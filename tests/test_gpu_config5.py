@@ -100,6 +100,9 @@ QUERIES = [  # (query text, top_k, complexity, extra CLI flags, oracle kwargs)
     ("vector database embedding search engines", 5, 48, ["--hybrid", "--hybrid-alpha", "0.25"], dict(hybrid=True, hybrid_alpha=0.25)),
     ("python asyncio event loop coroutine tasks", 3, 64, ["--hybrid", "-f", "source:*.py"], dict(hybrid=True, hybrid_alpha=0.7, filter_text="source:*.py")),
     ("rust ownership borrow checker lifetimes explained", 8, 100, ["--auto-hybrid", "false", "-f", "lines<40"], dict(filter_text="lines<40")),
+    # corrected polarity (`--compat-polarity false`): the ANN hits enter hybrid_rerank as 1 - dist
+    ("hybrid rerank normalise blend of scores", 5, 64, ["--hybrid", "--compat-polarity", "false"], dict(hybrid=True, hybrid_alpha=0.7, compat_polarity=False)),
+    ("diskann vamana", 4, 64, ["--compat-polarity", "false", "--hybrid-alpha", "0.4"], dict(hybrid=True, hybrid_alpha=0.4, compat_polarity=False)),
 ]
 
 
