@@ -51,6 +51,7 @@ WORKLOADS = {
     "hnsw1m": dict(rows=1_000_000, d=768, M=32, efc=128, ef=128),     # BASELINE configs[1]
     "hnsw100m_shard8": dict(rows=12_500_000, d=768, M=32, efc=200, ef=128),  # BASELINE configs[3]: 100M x 768 = 8 shards of 12.5M (--gpus 8)
     "hnsw100k": dict(rows=100_000, d=768, M=32, efc=128, ef=128),     # quick check
+    "hnsw4m": dict(rows=4_000_000, d=768, M=32, efc=200, ef=128),     # rehearsal size: 8 shards of it fit ONE GPU (--mode composite, LEANN_BENCH_COMPOSITE_DEVICES=0,0,...)
     # configs[4] search leg: DiskANN/Vamana, 1536-d.  R = 64 (R = 32 reaches recall 0.98 at 1M but only 0.60 at 10M with beam 128; 0.81 with a
     # second build pass, LEANN_VAMANA_PASSES=2: profiles/r02_vamana10m1536_r32_bench.json)
     "vamana10m1536": dict(rows=10_000_000, d=1536, M=64, efc=128, ef=128, backend=1),
