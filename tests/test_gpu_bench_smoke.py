@@ -1,0 +1,56 @@
+"""-m gpu: bench.py end to end on its smallest workload (hnsw100k: 100k x 768, seconds) — the contract's keys are there, the in-run checks
+(GPU == oracle on the sampled queries; device hybrid rerank == oracle/searcher_oracle.py) hold, and the default-run orchestration merges its
+legs into one line.  Guards the measurement harness itself; the numbers of record come from the full-size workloads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env=None):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                       env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "stdout must carry exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_and_in_run_identity_check(gpu):
+    j = _bench("--workload", "hnsw100k", "--steps", "3", "--warmup", "1", "--no-latency", "--cpu-queries", "512", "--small-batch", "64")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "recall_at_10"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["vs_baseline"] is None and j["dtype"] == "f32"
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert j["recall_at_10"] >= 0.95
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_results_bit_identical_on_sample"] is True
+    assert c["simd_value"] > 0
+    assert j["small_batch"]["batch"] == 64 and j["small_batch"]["ms_per_call"] > 0
+
+
+def test_bench_hybrid_leg_checks_itself_against_the_oracle(gpu):
+    j = _bench("--workload", "hnsw100k", "--hybrid", "--steps", "3", "--warmup", "1", "--no-latency", "--cpu-queries", "1024", "--compat-polarity", "false")
+    h = j["hybrid"]
+    assert h["fetch_k"] == 50 and h["compat_polarity"] is False and h["rerank_avg_ms"] > 0
+    assert h["rerank_parity"]["sample"] == 1024 and h["rerank_parity"]["mismatching_queries"] == 0
+    assert h["cpu_port_equals_numpy_restatement"] is True
+    assert j["cpu_baseline"]["gpu_results_bit_identical_on_sample"] is True
+
+
+def test_gpus_2_rehearsals_on_one_gpu(gpu):
+    """the N > 1 paths with what one GPU allows: two ranks over gloo sharing the device (started by bench.py itself), and two shards behind
+    one composite handle"""
+    j = _bench("--gpus", "2", "--workload", "hnsw100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency",
+               env={"LEANN_BENCH_DIST_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and "shard2" in j["config"]["parallelism"] and j["recall_at_10"] >= 0.95 and "replica_mode" in j
+    j = _bench("--gpus", "2", "--mode", "composite", "--workload", "hnsw100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency",
+               env={"LEANN_BENCH_COMPOSITE_DEVICES": "0,0"})
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"].startswith("composite2") and j["recall_at_10"] >= 0.95
