@@ -342,3 +342,36 @@ def test_sharded_recompute_search_equals_the_unsharded_handle(la, po, gpu, G):
     L.leann_recompute_close(comp)
     for p in parts + [one]:
         L.leann_recompute_close(p)
+
+
+def test_sharded_handle_on_distinct_devices(la, po, gpu):
+    """the `remote` branch of shard.hip (peer copies of queries, bitmap slices, result blocks and counters between devices)
+    has never run — every box of this pool has one GPU.  On a node with >= 2 GPUs this test puts one shard on each device and
+    demands the answers of the one-device composite handle; on a one-GPU box it is skipped (and says so)."""
+    G = la.device_count()
+    if G < 2:
+        pytest.skip("one GPU visible: the multi-device path stays unexercised (DESIGN.md §10)")
+    G = min(G, 8)
+    n, d, nq, k, ef, M = 8192 + 640, 128, 40, 10, 48, 12
+    X = synth(po, n, d)
+    Q = synth(po, nq, d, stream=1)
+    lows = [0] + [((n * g) // G) & ~63 for g in range(1, G)] + [n]
+    rows = [lows[g + 1] - lows[g] for g in range(G)]
+    same = [la.DeviceArray.from_host(X[lows[g]:lows[g + 1]]) for g in range(G)]
+    ref = la.ShardedIndex.build_device(la.BackendType.Hnsw, [p.ptr for p in same], rows, d, d, M, 48, [0] * G, keep=same).as_backend()
+    spread = [la.DeviceArray.from_host(X[lows[g]:lows[g + 1]], device=g) for g in range(G)]
+    s = la.ShardedIndex.build_device(la.BackendType.Hnsw, [p.ptr for p in spread], rows, d, d, M, 48, list(range(G)), keep=spread).as_backend()
+    rk, rd, rc = ref.search_batch(Q, k, ef)
+    gk, gd, gc = s.search_batch(Q, k, ef)
+    assert (gk == rk).all() and (gd == rd).all() and (gc == rc).all()
+    rng = np.random.default_rng(3)
+    dense = np.packbits(rng.random(n) < 0.3, bitorder="little")
+    sparse = np.packbits(rng.random(n) < 0.01, bitorder="little")
+    assert all((a == b).all() for a, b in zip(s.search_filtered_batch(Q, k, ef, dense), ref.search_filtered_batch(Q, k, ef, dense)))
+    assert all((a == b).all() for a, b in zip(s.search_filtered_exact_batch(Q, k, sparse), ref.search_filtered_exact_batch(Q, k, sparse)))
+    f, fr = s.register_filter(sparse), ref.register_filter(sparse)
+    assert all((a == b).all() for a, b in zip(s.search_filter_batch(Q, k, ef, f, mode="auto"), ref.search_filter_batch(Q, k, ef, fr, mode="auto")))
+    f.close(); fr.close()
+    k1, d1 = s.search(Q[3], k, ef)
+    assert (k1 == rk[3]).all() and (d1 == rd[3]).all()
+    s.close(); ref.close()
