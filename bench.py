@@ -850,7 +850,7 @@ def main():
     # recall that goes into the record is measured on the OTHER half (disjoint queries: no tuning on the reported set)
     half = nrq // 2 if ef_auto and nrq >= 200 else 0
     if ef_auto and not (allow is not None and args.filter_exact):
-        for cand in (40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 88, 96, 104, 112, 120, 128):
+        for cand in (*range(40, 65, 2), 68, 72, 76, 80, 88, 96, 104, 112, 120, 128):
             ef = cand
             if measure_recall(0, half or nrq) >= 0.955:
                 break
@@ -858,7 +858,7 @@ def main():
     recall = measure_recall(half, nrq)
     bumped = False
     while ef_auto and half and recall < 0.95 and ef < 128:  # guard only: the metric is defined at recall >= 0.95 on the REPORTED queries
-        ef = min(128, ef + (4 if ef < 64 else 8))
+        ef = min(128, ef + (2 if ef < 64 else 8))
         recall, bumped = measure_recall(half, nrq), True
     log(f"recall@{k} = {recall:.4f} at ef={ef} (recall queries [{half}, {nrq}), corpus {corpus_total} x {d})" + (" [ef raised after the report-half check]" if bumped else ""))
 
