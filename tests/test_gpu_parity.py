@@ -231,6 +231,32 @@ def test_gpu_built_vamana(la, po, gpu, tmp_path):
     s.close()
 
 
+@pytest.mark.parametrize("knobs", [{"LEANN_VAMANA_TWO_STAGE": "0"}, {"LEANN_VAMANA_NAV": "1"}, {"LEANN_VAMANA_PASSES": "2", "LEANN_VAMANA_ALPHA1_PCT": "100"},
+                                   {"LEANN_VAMANA_PENDING": "0"}])
+def test_vamana_builder_knobs_produce_searchable_graphs(la, po, gpu, monkeypatch, tmp_path, knobs):
+    """the construction knobs behind profiles/r03_vamana_scale.md (one-stage prune, entry layers, DiskANN's two-pass schedule, strict
+    back-edges): each builds a valid graph — the kernel's walk == the oracle's on the exported arrays, levels included — saves, reloads
+    and finds its neighbours."""
+    for kname, v in knobs.items():
+        monkeypatch.setenv(kname, v)  # (read once per build)
+    n, d, R = 6000, 96, 16
+    X = synth(po, n, d)
+    Q = synth(po, 64, d, stream=1)
+    dX = la.DeviceArray.from_host(X)
+    s = la.BackendSearcher.build_device(la.BackendType.DiskAnn, dX.ptr, n, d, d, R, 48)
+    g = s.graph_export()
+    assert (g["max_level"] > 0) == ("LEANN_VAMANA_NAV" in knobs) and g["M0"] == R
+    G = po.Graph.from_arrays(X, g["M"], g["M0"], g["max_level"], g["entry"], g["levels"], g["upper_off"], g["adj0"], g["adjU"])
+    gk = _assert_same(po, G, s, Q, 10, 48, algo=1)
+    assert recall_at_k(gk, po.exact_topk(X, Q, 10)) >= 0.9
+    stem = str(tmp_path / "documents.leann")
+    s.save(stem)
+    s2 = la.DiskAnnSearcher.load(stem, d)
+    k2, d2, _ = s2.search_batch(Q, 10, 48)
+    assert (k2 == gk).all()
+    s.close(); s2.close()
+
+
 def test_scan_topk_matches_recompute_restatement(la, po, gpu):
     n, d, nq, k = 5000, 768, 9, 10
     X = synth(po, n, d)
