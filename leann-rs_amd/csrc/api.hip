@@ -64,6 +64,7 @@ static LeannKnobs *read_knobs_from_env() {
     k->no_list = flag("LEANN_RECOMPUTE_NO_LIST");
     k->no_tiled = flag("LEANN_RECOMPUTE_NO_TILED");
     k->hnsw_reference_ef = flag("LEANN_HNSW_REFERENCE_EF");
+    k->force_remote = flag("LEANN_DEBUG_FORCE_REMOTE");
     if (const char *e = getenv("LEANN_COALESCE")) k->coalesce_off = !strcmp(e, "off") || !strcmp(e, "0");
     if (const char *e = getenv("LEANN_STAMP_BUF")) k->stamp_buf = strtoull(e, nullptr, 0);
     return k;

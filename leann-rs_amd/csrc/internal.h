@@ -32,6 +32,8 @@ struct LeannKnobs {
     int nw = 0;             // LEANN_DEBUG_NW: waves per query (0 = by batch size)
     int gpool_bits = 0, gpool2_bits = 0; // LEANN_DEBUG_GPOOL_BITS / _GPOOL2_BITS (0 = default sizes)
     bool no_feat256 = false, no_zero_copy = false, no_emit = false, fused_v1 = false, no_list = false, no_tiled = false;
+    bool force_remote = false;       // LEANN_DEBUG_FORCE_REMOTE: sharded searches treat EVERY shard as if it sat on another device (staging
+                                     // buffers + peer copies, with source = destination device) — exercises that branch on a one-GPU box
     bool coalesce_off = false;       // LEANN_COALESCE=off|0
     bool hnsw_reference_ef = false;  // LEANN_HNSW_REFERENCE_EF=1: HNSW handles opened from now on search with ef = 64 whatever
                                      // `complexity` says, as the reference does (hnsw.rs:49 expansion_search: 64, :83 _complexity unused)

@@ -709,7 +709,7 @@ static int sharded_recompute_search(leann_recompute *r, const float *d_queries, 
         auto fail = [&](const char *what) { leann_set_error("sharded recompute search, part %zu: %s failed: %s", g, what, hipGetErrorString(hipGetLastError())); return (int)LEANN_ERR_DEVICE; };
         if (hipSetDevice(p->device) != hipSuccess) return fail("hipSetDevice");
         if (hipStreamWaitEvent(pt.st, r->ev_q, 0) != hipSuccess) return fail("hipStreamWaitEvent");
-        const bool remote = p->device != r->device;
+        const bool remote = p->device != r->device || leann_knobs().force_remote;
         const size_t mask_off = (size_t)((p->key_offset - r->key_offset) / 8), mask_b = d_allow_mask ? (p->n + 7) / 8 : 0;
         const float *q = d_queries;
         const uint8_t *mask = d_allow_mask ? d_allow_mask + mask_off : nullptr;

@@ -563,7 +563,7 @@ int leann_internal_sharded_search(leann_sharded *s, const float *d_queries, size
             HIP_CHECK_RET(hipSetDevice(sd.device));
             HIP_CHECK_RET(hipStreamWaitEvent(sd.st, sl.ev_q, 0));
             if (sl.used) HIP_CHECK_RET(hipStreamWaitEvent(sd.st, sl.done, 0)); // the merge that last read this slot has finished
-            const bool remote = sd.device != s->primary;
+            const bool remote = sd.device != s->primary || leann_knobs().force_remote;
             const float *q = d_queries;
             const uint8_t *allow_g = d_allow ? d_allow + sd.lo / 8 : nullptr; // the shard's slice of the bitmap(s): its first position is bit 0
             unsigned char *blkp = sl.gather + g * blk;

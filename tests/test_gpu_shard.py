@@ -375,3 +375,73 @@ def test_sharded_handle_on_distinct_devices(la, po, gpu):
     k1, d1 = s.search(Q[3], k, ef)
     assert (k1 == rk[3]).all() and (d1 == rd[3]).all()
     s.close(); ref.close()
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_remote_shard_branch_on_one_device(la, po, gpu, monkeypatch, G):
+    """The multi-device code of shard.hip / sharded_recompute_search (staging buffers on the shard's device, peer copies of queries,
+    bitmap slices, result blocks and counters, cross-stream events) cannot meet a second GPU on this pool.  LEANN_DEBUG_FORCE_REMOTE=1
+    makes every shard take that branch with source = destination device: the logic — offsets, sizes, slices, ordering — is the same,
+    only the copies stay on one device.  Answers must equal the ordinary one-device composite handle's."""
+    import ctypes as C
+    n, d, nq, k, ef, M = 8192 + 640, 128, 40, 10, 48, 12
+    X = synth(po, n, d)
+    Q = synth(po, nq, d, stream=1)
+    lows = [0] + [((n * g) // G) & ~63 for g in range(1, G)] + [n]
+    parts = [la.DeviceArray.from_host(X[lows[g]:lows[g + 1]]) for g in range(G)]
+    s = la.ShardedIndex.build_device(la.BackendType.Hnsw, [p.ptr for p in parts], [lows[g + 1] - lows[g] for g in range(G)], d, d, M, 48,
+                                     [0] * G, keep=parts).as_backend()
+    rng = np.random.default_rng(G)
+    dense = np.packbits(rng.random(n) < 0.3, bitorder="little")
+    sparse = np.packbits(rng.random(n) < 0.01, bitorder="little")
+    per_query = np.stack([np.packbits(rng.random(n) < 0.2, bitorder="little") for _ in range(nq)])
+    f = s.register_filter(sparse)
+
+    def everything():
+        dQ = la.DeviceArray.from_host(Q)
+        ok, od, oc, st = (la.DeviceArray((nq, k), np.uint64), la.DeviceArray((nq, k), np.float32), la.DeviceArray(nq, np.uint32),
+                          la.DeviceArray((nq, 4), np.uint32))
+        s.search_batch_device(dQ.ptr, nq, k, ef, ok.ptr, od.ptr, oc.ptr, d_stats=st.ptr)
+        la.sync()
+        return [s.search_batch(Q, k, ef), s.search_filtered_batch(Q, k, ef, dense), s.search_filtered_batch(Q, k, ef, per_query),
+                s.search_filtered_exact_batch(Q, k, sparse), s.search_filter_batch(Q, k, ef, f, mode="walk"),
+                s.search_filter_batch(Q, k, ef, f, mode="exact"), (ok.to_host(), od.to_host(), oc.to_host(), st.to_host())]
+    ref = everything()
+    monkeypatch.setenv("LEANN_DEBUG_FORCE_REMOTE", "1")
+    la.lib().leann_debug_reload_env()
+    got = everything()
+    for a, b in zip(ref, got):
+        assert all((x == y).all() for x, y in zip(a, b))
+    f.close()
+    s.close()
+    # the sharded recompute search takes its remote branch too
+    L, chk = la.lib(), la._native.check
+    nr, h, dd = 6000, 256, 768
+    F = po.synth_features(0x5EED0001, h, 64, 1.0, 0, 0, nr)
+    W = po.synth_weights(0x5EED0001, h, dd)
+    Qr = po.recompute_encode(po.synth_features(0x5EED0001, h, 64, 1.0, 1, 0, 33), W)
+    dF, dW, dQ = la.DeviceArray.from_host(F), la.DeviceArray.from_host(W), la.DeviceArray.from_host(Qr)
+    lo2 = [0] + [((nr * g) // G) & ~63 for g in range(1, G)] + [nr]
+    hs = []
+    for g in range(G):
+        p = C.c_void_p()
+        chk(L.leann_recompute_create(dF.ptr + lo2[g] * h * 2, lo2[g + 1] - lo2[g], h, dW.ptr, dd, 0, lo2[g], C.byref(p)))
+        hs.append(p)
+    comp = C.c_void_p()
+    chk(L.leann_recompute_create_sharded((C.c_void_p * G)(*hs), G, C.byref(comp)))
+    mask = la.DeviceArray.from_host(np.packbits(rng.random(nr) < 0.2, bitorder="little"))
+    outs = []
+    for force in ("1", None):
+        if force is None:
+            monkeypatch.delenv("LEANN_DEBUG_FORCE_REMOTE")
+        L.leann_debug_reload_env()
+        for m in (None, mask):
+            dk, ds, dc = la.DeviceArray((33, k), np.uint64), la.DeviceArray((33, k), np.float32), la.DeviceArray(33, np.uint32)
+            chk(L.leann_recompute_search_batch_device(comp, dQ.ptr, 33, k, m.ptr if m else None, dk.ptr, ds.ptr, dc.ptr, None))
+            la.sync()
+            outs.append((dk.to_host(), ds.to_host(), dc.to_host()))
+    for a, b in zip(outs[:2], outs[2:]):
+        assert all((x == y).all() for x, y in zip(a, b))
+    L.leann_recompute_close(comp)
+    for p in hs:
+        L.leann_recompute_close(p)
