@@ -43,7 +43,7 @@ def main():
     ef = b["config"]["ef_search"]
     assert ef == bf["config"]["ef_search"]
     json.dump({"workload": "hnsw10m", "ef_search": ef, "ef_construction": b["config"]["ef_construction"], "kernel": "beam_search_kernel<3,4,4,false>",
-               "launch": "16384 queries, k=10, 10M x 768 f32", "round": 2, "FETCH_SIZE_KB_per_launch": fe / 1024, "WRITE_SIZE_KB_per_launch": wr / 1024,
+               "launch": "16384 queries, k=10, 10M x 768 f32", "round": ROUND, "FETCH_SIZE_KB_per_launch": fe / 1024, "WRITE_SIZE_KB_per_launch": wr / 1024,
                "fetch_bytes_raw": fe, "fetch_bytes_corrected_x2_gfx950": 2 * fe, "write_bytes": wr, "hbm_bytes_per_launch": 2 * fe + wr,
                "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (2 * fe + wr) / alg, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
                "l2_hit_rate": hit / (hit + miss),
@@ -121,20 +121,21 @@ def other_kernels():
                     wr = sum(last_n(pw, "WRITE_SIZE", 4)) / 4 * 1024
                     alg = bf["roofline"]["algorithmic_bytes_per_launch"]
                     json.dump({"workload": wl, "ef_search": bf["config"]["ef_search"], "kernel": "beam_search_feat256_kernel<1,4>",
-                               "launch": "16384 queries, k=10, 10M x (256 bf16 features + f32 norm)", "round": 2, "fetch_bytes_raw": fe,
+                               "launch": "16384 queries, k=10, 10M x (256 bf16 features + f32 norm)", "round": ROUND, "fetch_bytes_raw": fe,
                                "fetch_bytes_corrected_x2_gfx950": 2 * fe, "write_bytes": wr, "hbm_bytes_per_launch": 2 * fe + wr,
                                "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (2 * fe + wr) / alg,
                                "method": "separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE), --kernel-include-regex on the query kernel, last 4 launches of "
                                          "`bench.py --workload recompute10m_graph --no-cpu-baseline --no-latency --steps 4 --warmup 1` (scripts/profile_side.sh); "
-                                         "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; a 520-B row at an 8-byte aligned offset touches 5.06 lines of 128 B = "
-                                         "648 B on average, i.e. 1.25 x its algorithmic bytes"},
+                                         "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; split device layout (round 3): a 512-B feature row is four whole 128-B lines and the "
+                                         "4-byte gather of its norm costs a fifth = 640 B per evaluated row, 1.24 x its 516 algorithmic bytes (the inline 520-B row of round 2 "
+                                         "touched 5.06 lines = 648 B)"},
                               open(os.path.join(dst, f"pmc_traffic_{wl}.json"), "w"), indent=1)
                     lines.append(f"* PMC (separate passes): FETCH_SIZE x 2 + WRITE_SIZE = {(2 * fe + wr) / 1e9:.2f} GB per launch = {(2 * fe + wr) / alg:.3f} x the algorithmic "
-                                 f"{alg / 1e9:.2f} GB (whole 128-B lines: a 520-B row touches 5.06 of them = 1.25 x) -> {(2 * fe + wr) / 1e9 / r['kernel_avg_ms']:.2f} TB/s of line traffic")
+                                 f"{alg / 1e9:.2f} GB (whole 128-B lines: four for the 512-B feature row + one for the 4-byte norm gather = 1.24 x) -> {(2 * fe + wr) / 1e9 / r['kernel_avg_ms']:.2f} TB/s of line traffic")
                 except Exception as e:  # noqa: BLE001
                     lines.append(f"* PMC traffic pass: failed ({e})")
             lines.append(f"* bench.py HIP-event average of the timed launches: {r['kernel_avg_ms']:.3f} ms; algorithmic bytes per query {r['algorithmic_bytes_per_query']:.0f} "
-                         f"({r['dist_evals_per_query']:.0f} evaluations x 520 B + {r['hops_per_query']:.0f} hops x 256 B); ceiling for random 520-B rows read four per instruction: 10 G rows/s = 5.2 TB/s algorithmic = 6.4 TB/s in whole 128-B lines (`r02_gather_ceiling.txt`)")
+                         f"({r['dist_evals_per_query']:.0f} evaluations x 516 B + {r['hops_per_query']:.0f} hops x 256 B); ceiling for random 520-B rows read four per instruction: 10 G rows/s = 5.2 TB/s algorithmic = 6.4 TB/s in whole 128-B lines (`r02_gather_ceiling.txt`)")
         lines.append("")
     pm = os.path.join(src, "prof_mfma", ROUND + "_counter_collection.csv")
     if os.path.exists(pm):
