@@ -513,6 +513,9 @@ def main():
     ap.add_argument("--clusters", type=int, default=None,
                     help="number of cluster centres of the synthetic corpus (default 4096).  65536 puts (almost) every query of a 16 384-query "
                          "launch into a cluster of its own: bounds what queries sharing a neighbourhood gain from L2 / Infinity Cache")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1, modes shard / composite: STRONG scaling — the workload's rows are the WHOLE corpus, split N ways (rows / N per GPU), instead of "
+                         "rows per GPU (weak scaling, the default).  SURVEY.md §8e: every GPU still processes every query, so expect little gain.")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the workload itself.  Without it (and without --workload) the default run measures the headline AND compact legs "
                          "of every other 1-GPU BASELINE config, each in a child process, and reports them under `other_configs` of the one line")
@@ -588,6 +591,9 @@ def main():
     if wl.get("kind") == "recompute":
         return bench_recompute(args, wl, la, L, chk, dev, local_rank, world, rank, dist, log)
     rows, d, M, efc = wl["rows"], wl["d"], wl["M"], (args.efc or wl["efc"])
+    strong = bool(args.strong) and args.gpus > 1 and args.mode in ("shard", "composite")
+    if strong:
+        rows = (rows // args.gpus) & ~63  # the workload's rows are the whole corpus (multiples of 64 per shard: bitmaps slice at bytes)
     ef_auto = str(args.ef).lower() == "auto"
     ef = wl["ef"] if ef_auto else (int(args.ef) or wl["ef"])
     backend = wl.get("backend", 0)
@@ -980,7 +986,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",

@@ -54,3 +54,8 @@ def test_gpus_2_rehearsals_on_one_gpu(gpu):
     j = _bench("--gpus", "2", "--mode", "composite", "--workload", "hnsw100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency",
                env={"LEANN_BENCH_COMPOSITE_DEVICES": "0,0"})
     assert j["n_gpus"] == 2 and j["config"]["parallelism"].startswith("composite2") and j["recall_at_10"] >= 0.95
+    assert j["scaling"] == "weak" and j["config"]["corpus_rows_total"] == 200_000
+    # --strong: the workload's rows are the whole corpus, split over the shards
+    j = _bench("--gpus", "2", "--mode", "composite", "--strong", "--workload", "hnsw100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency",
+               env={"LEANN_BENCH_COMPOSITE_DEVICES": "0,0"})
+    assert j["scaling"] == "strong" and j["config"]["rows_per_gpu"] == 49_984 and j["config"]["corpus_rows_total"] == 2 * 49_984
