@@ -41,7 +41,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch  # device memory, streams, events, torch.distributed (RCCL): plumbing only
+
+torch = None  # imported by main() on the paths that touch the GPU (device memory, streams, events, torch.distributed / RCCL: plumbing only);
+              # the launcher-less parents (default run, --gpus N) only start children and need neither torch nor a GPU
 
 WORKLOADS = {
     # name: rows per GPU, dims, M, efc, ef, synthetic params
@@ -549,6 +551,9 @@ def main():
         # `python bench.py --gpus N` without a launcher (the driver's command shape): this process has not touched the GPU yet, so
         # it starts the N ranks itself as a CHILD process and relays rank 0's JSON line
         sys.exit(self_launch(args, sys.argv[1:]))
+    global torch
+    import torch as _torch
+    torch = _torch
     quiet_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

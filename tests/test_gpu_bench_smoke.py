@@ -59,3 +59,11 @@ def test_gpus_2_rehearsals_on_one_gpu(gpu):
     j = _bench("--gpus", "2", "--mode", "composite", "--strong", "--workload", "hnsw100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency",
                env={"LEANN_BENCH_COMPOSITE_DEVICES": "0,0"})
     assert j["scaling"] == "strong" and j["config"]["rows_per_gpu"] == 49_984 and j["config"]["corpus_rows_total"] == 2 * 49_984
+
+
+def test_default_run_parent_needs_no_gpu_and_relays_one_line(gpu):
+    """the driver's command shape (no --workload): the parent only starts children — here the headline leg alone (LEANN_BENCH_SKIP_OTHERS) at
+    2 steps — and prints ONE line with the `other_configs` key"""
+    j = _bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency", env={"LEANN_BENCH_SKIP_OTHERS": "1"})
+    assert j["steps"] == 2 and j["warmup"] == 1 and j["n_gpus"] == 1 and j["config"]["rows_per_gpu"] == 10_000_000
+    assert j["other_configs"] == {} and j["recall_at_10"] >= 0.95 and 0.5 < j["roofline"]["frac"] < 1
