@@ -388,7 +388,29 @@ def self_launch(args, argv, run=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     env["LEANN_BENCH_SELF_LAUNCHED"] = "1"
-    run = run or (lambda cmd: subprocess.run(cmd, env=env, stdout=subprocess.PIPE))
+    def run_with_deadline(cmd, limit_s):
+        # a rank that hangs (e.g. an RCCL bootstrap that never completes) must not eat the whole run: past the deadline the child's own
+        # process group — the one started here, nothing else — is ended and the fallback gets its turn
+        import signal
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            print(f"[bench] {' '.join(cmd[:4])} ... gave no result within {limit_s:.0f} s: ending its process group", file=sys.stderr, flush=True)
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+                out, _ = p.communicate(timeout=20)
+            except Exception:  # noqa: BLE001
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except Exception:  # noqa: BLE001
+                    pass
+                out, _ = p.communicate()
+            return subprocess.CompletedProcess(cmd, -9, out, None)
+        return subprocess.CompletedProcess(cmd, p.returncode, out, None)
+    limit_ranks = float(os.environ.get("LEANN_BENCH_LAUNCH_TIMEOUT_S", "330"))
+    injected = run is not None
+    run = run or (lambda cmd: run_with_deadline(cmd, limit_ranks if "torch.distributed.run" in cmd else 3600.0))
 
     def relay(proc):
         lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]

@@ -103,3 +103,18 @@ def test_default_run_reports_every_one_gpu_config_in_one_line(capsys, monkeypatc
     assert b.run_all_configs(args, [], run=run) == 0
     line = json.loads(capsys.readouterr().out.strip())
     assert all("skipped" in v for v in line["other_configs"].values())
+
+
+def test_hanging_ranks_are_ended_at_the_deadline_and_the_fallback_runs(capsys, monkeypatch):
+    """a rank that never returns (an RCCL bootstrap that hangs) must not eat the run: past LEANN_BENCH_LAUNCH_TIMEOUT_S the child's own
+    process group is ended and the composite fallback gets its turn"""
+    import time
+    b = _bench()
+    monkeypatch.setenv("LEANN_BENCH_LAUNCH_TIMEOUT_S", "2")
+    monkeypatch.setattr(b, "launch_command", lambda n, port, argv: [sys.executable, "-c", "import time; time.sleep(120)", "torch.distributed.run"])
+    monkeypatch.setattr(b, "composite_command", lambda argv: [sys.executable, "-c", "print('{\"n_gpus\": 2, \"config\": {\"parallelism\": \"composite2\"}}')"])
+    args = types.SimpleNamespace(gpus=2, workload="hnsw100k", mode="shard")
+    t0 = time.time()
+    assert b.self_launch(args, ["--gpus", "2"]) == 0
+    assert time.time() - t0 < 40
+    assert "composite2" in capsys.readouterr().out
