@@ -408,7 +408,7 @@ def self_launch(args, argv, run=None):
                 out, _ = p.communicate()
             return subprocess.CompletedProcess(cmd, -9, out, None)
         return subprocess.CompletedProcess(cmd, p.returncode, out, None)
-    limit_ranks = float(os.environ.get("LEANN_BENCH_LAUNCH_TIMEOUT_S", "330"))
+    limit_ranks = float(os.environ.get("LEANN_BENCH_LAUNCH_TIMEOUT_S", "360"))
     injected = run is not None
     run = run or (lambda cmd: run_with_deadline(cmd, limit_ranks if "torch.distributed.run" in cmd else 3600.0))
 
