@@ -458,7 +458,7 @@ def summarise_leg(j):
          "kernel": (r.get("kernel") or "").split(" (")[0], "kernel_avg_ms": r.get("kernel_avg_ms", r.get("fused_encode_score_ms"))}
     # numbers only: the explanatory strings live in the leg's own line (`command` reproduces it); the one line stays a few KB
     if "small_batch" in j:
-        o["small_batch"] = {k: j["small_batch"].get(k) for k in ("batch", "ms_per_call", "value", "hbm_frac")}
+        o["small_batch"] = {k: j["small_batch"].get(k) for k in ("batch", "ms_per_call", "value", "hbm_frac", "streams_in_flight", "value_concurrent")}
     if "hybrid" in j:
         h = j["hybrid"]
         o["hybrid"] = {k: h.get(k) for k in ("fetch_k", "alpha", "compat_polarity", "rerank_avg_ms", "traversal_avg_ms")}
@@ -1093,6 +1093,29 @@ def main():
                               "hbm_frac": bytes_per_query * sb / dt / 1e9 / HBM_PEAK_GBS,
                               "note": f"{reps} back-to-back device calls of {sb} queries (latency form of the hop loop, 16 waves per query): "
                                       "a latency regime, not a bandwidth one"}
+        # the same calls with several of them in flight (a server's concurrent requests, one HIP stream each): a call of 64 queries
+        # occupies 64 of the 256 CUs, so independent calls overlap; per-call latency stays what it is, the rate does not
+        ns_ = 8
+        sts = [torch.cuda.Stream(device=dev) for _ in range(ns_)]
+        bufs = [(torch.empty((sb, kk), dtype=torch.int64, device=dev), torch.empty((sb, kk), dtype=torch.float32, device=dev),
+                 torch.empty((sb,), dtype=torch.int32, device=dev)) for _ in range(ns_)]
+        nslice = max(1, (n_pool * B) // sb)
+
+        def fire(r_):
+            i = r_ % ns_
+            searcher.search_batch_device(Q.data_ptr() + (r_ % nslice) * sb * ld * 4, sb, kk, ef, bufs[i][0].data_ptr(), bufs[i][1].data_ptr(),
+                                         bufs[i][2].data_ptr(), None, C.c_void_p(sts[i].cuda_stream))
+        for r_ in range(4 * ns_):
+            fire(r_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r_ in range(reps * 2):
+            fire(r_)
+        torch.cuda.synchronize()
+        dt8 = (time.perf_counter() - t0) / (reps * 2)
+        out["small_batch"].update({"streams_in_flight": ns_, "value_concurrent": sb / dt8, "ms_per_call_concurrent": dt8 * 1e3,
+                                   "concurrent_note": f"{reps * 2} calls of {sb} queries issued round-robin on {ns_} HIP streams (per-call latency unchanged; "
+                                                      "value_concurrent = queries/s with the calls overlapping)"})
     if hybrid:
         rr_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
         out["hybrid"] = {"fetch_k": kk, "alpha": args.hybrid_alpha, "compat_polarity": compat,
