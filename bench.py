@@ -458,7 +458,7 @@ def summarise_leg(j):
          "kernel": (r.get("kernel") or "").split(" (")[0], "kernel_avg_ms": r.get("kernel_avg_ms", r.get("fused_encode_score_ms"))}
     # numbers only: the explanatory strings live in the leg's own line (`command` reproduces it); the one line stays a few KB
     if "small_batch" in j:
-        o["small_batch"] = {k: j["small_batch"].get(k) for k in ("batch", "ms_per_call", "value", "hbm_frac", "streams_in_flight", "value_concurrent")}
+        o["small_batch"] = {k: j["small_batch"].get(k) for k in ("batch", "ms_per_call", "value", "hbm_frac", "streams_in_flight", "value_concurrent", "value_concurrent_hipgraph")}
     if "hybrid" in j:
         h = j["hybrid"]
         o["hybrid"] = {k: h.get(k) for k in ("fetch_k", "alpha", "compat_polarity", "rerank_avg_ms", "traversal_avg_ms")}
@@ -1113,6 +1113,32 @@ def main():
             fire(r_)
         torch.cuda.synchronize()
         dt8 = (time.perf_counter() - t0) / (reps * 2)
+        # ... and the same 8 concurrent calls captured ONCE into a HIP graph (fork / join over the 8 streams) and replayed: the host then
+        # issues one graph launch per 8 calls instead of 16 kernel launches through the interpreter (launch-bound loops belong in graphs)
+        graph_qps = None
+        try:
+            cap = torch.cuda.Stream(device=dev)
+            gr = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gr, stream=cap):
+                for i in range(ns_):  # fork ...
+                    sts[i].wait_stream(cap)
+                for i in range(ns_):
+                    fire(i)
+                for i in range(ns_):  # ... join
+                    cap.wait_stream(sts[i])
+            for _ in range(5):
+                gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps // 2):
+                gr.replay()
+            torch.cuda.synchronize()
+            graph_qps = ns_ * sb * (reps // 2) / (time.perf_counter() - t0)
+        except Exception as e:  # noqa: BLE001  (capture is an extra; the line does not depend on it)
+            log("HIP-graph capture of the small-batch calls failed:", str(e)[:200])
+            torch.cuda.synchronize()
+        out["small_batch"]["value_concurrent_hipgraph"] = graph_qps
         out["small_batch"].update({"streams_in_flight": ns_, "value_concurrent": sb / dt8, "ms_per_call_concurrent": dt8 * 1e3,
                                    "concurrent_note": f"{reps * 2} calls of {sb} queries issued round-robin on {ns_} HIP streams (per-call latency unchanged; "
                                                       "value_concurrent = queries/s with the calls overlapping)"})
