@@ -33,7 +33,10 @@ def test_bench_line_contract_and_in_run_identity_check(gpu):
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_results_bit_identical_on_sample"] is True
     assert c["simd_value"] > 0
-    assert j["small_batch"]["batch"] == 64 and j["small_batch"]["ms_per_call"] > 0
+    sb = j["small_batch"]
+    assert sb["batch"] == 64 and sb["ms_per_call"] > 0
+    # independent small calls overlap (8 streams), and the 8 calls replay from ONE HIP graph: the device entry points are capturable
+    assert sb["value_concurrent"] > sb["value"] and sb["value_concurrent_hipgraph"] is not None and sb["value_concurrent_hipgraph"] > sb["value"]
 
 
 def test_bench_hybrid_leg_checks_itself_against_the_oracle(gpu):
